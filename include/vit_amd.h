@@ -1,0 +1,148 @@
+/*
+ * vit_amd.h -- C ABI of libvit_amd.so: MI355X (gfx950) ViT encoder forward path.
+ *
+ * Boundary note. The reference repository has NO plugin / operator / FFI interface for a
+ * vision encoder: its only boundary to a vision model is a network RPC that ships an
+ * encoded image file and gets text back --
+ *   ollama.Client.generate(model, prompt, images=[b64])      Vlm_coder.py:205, :381
+ *   GenerativeModel.generate_content([prompt, Image])        vlm_cad.py:171
+ * (SURVEY.md section 8b). The entry points below are therefore what a local encoder in
+ * front of those call sites binds: tensors in, embeddings out. Each kernel entry point
+ * cites the definition it computes (transformers 5.15.0 `models/vit/modeling_vit.py` =
+ * "MV", `models/clip/modeling_clip.py` = "MC"), which is the specification SURVEY.md
+ * section 8a pins this build to.
+ *
+ * Conventions
+ *  - Plain C: pointers and sizes only. `stream` is a hipStream_t passed as void*
+ *    (NULL = the null stream). Every pointer named *_dev / documented "device" is device
+ *    memory owned by the CALLER, valid until the stream has executed the call.
+ *  - All calls return 0 on success or a negative VIT_E_* code; vit_last_error() returns a
+ *    thread-local human-readable message for the last failure. No exceptions cross the ABI.
+ *  - Launches are asynchronous on `stream`. Nothing on the hot path (vit_forward and the
+ *    per-kernel entry points) allocates, frees or synchronises.
+ *  - A vit_ctx is bound to the device that was current at vit_create and is not
+ *    thread-safe: one context per device / stream.
+ *  - dtype codes: VIT_F32 = 0, VIT_BF16 = 1. In VIT_BF16 mode matrices and activations are
+ *    bf16, all accumulation / LayerNorm statistics / softmax are fp32, and vectors (biases,
+ *    LayerNorm affine, position / class embeddings) stay fp32.
+ */
+#ifndef VIT_AMD_H
+#define VIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIT_F32 0
+#define VIT_BF16 1
+
+#define VIT_VARIANT_VIT 0  /* HF ViTModel semantics: final LayerNorm over all tokens (MV:385) */
+#define VIT_VARIANT_CLIP 1 /* HF CLIPVisionModel: pre_layrnorm, un-normed hidden, post_layernorm(CLS) (MC:641-656) */
+
+#define VIT_ACT_GELU 0       /* exact erf GELU (configuration_vit.py:54) */
+#define VIT_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x) (configuration_clip.py:105) */
+
+/* epilogue codes of vit_gemm_bias_act */
+#define VIT_EPI_BIAS 0       /* C = A W^T + bias                       (q/k/v: MV:216-218) */
+#define VIT_EPI_GELU 1       /* C = gelu(A W^T + bias)                 (fc1:  MV:250-251) */
+#define VIT_EPI_QUICK_GELU 2 /* C = quick_gelu(A W^T + bias)           (CLIP fc1) */
+#define VIT_EPI_RESIDUAL 3   /* C = A W^T + bias + residual            (o_proj+res MV:236,277; fc2+res MV:252,284) */
+
+#define VIT_OK 0
+#define VIT_E_INVALID (-1)   /* bad argument / unsupported shape */
+#define VIT_E_STATE (-2)     /* weights missing, wrong device, ... */
+#define VIT_E_HIP (-3)       /* a HIP runtime call failed */
+#define VIT_E_NOMEM (-4)     /* workspace too small / allocation failed */
+
+typedef struct vit_ctx vit_ctx;
+
+/* Field names follow ViTConfig (configuration_vit.py:50-65). */
+typedef struct vit_config {
+    int32_t hidden_size;         /* D */
+    int32_t num_hidden_layers;   /* L */
+    int32_t num_attention_heads; /* H */
+    int32_t intermediate_size;   /* F */
+    int32_t image_size;          /* square input, pixels */
+    int32_t patch_size;          /* P */
+    int32_t num_channels;        /* C */
+    int32_t hidden_act;          /* VIT_ACT_* */
+    int32_t variant;             /* VIT_VARIANT_* */
+    int32_t qkv_bias;            /* 0/1 */
+    int32_t dtype;               /* compute dtype VIT_F32 | VIT_BF16 */
+    float layer_norm_eps;
+} vit_config;
+
+/* ---- library ---- */
+const char* vit_last_error(void);
+/* ABI version: bumped when a signature changes. */
+int vit_abi_version(void);
+
+/* ---- context: weights live in one arena allocated here (NOT on the hot path) ---- */
+int vit_create(const vit_config* cfg, vit_ctx** out);
+int vit_destroy(vit_ctx* ctx);
+
+/* Copy/convert one tensor of an HF state dict into the arena. `name` is the HF key
+ * (SURVEY.md 8a row a11), e.g. "layers.3.attention.q_proj.weight" (ViT) or
+ * "encoder.layers.3.self_attn.q_proj.weight" (CLIP). q/k/v are packed into one [3D, D]
+ * matrix so the three projections (MV:216-218) run as one GEMM. `src_dev` is device
+ * memory of `src_dtype` (VIT_F32 or VIT_BF16) holding `numel` contiguous elements. */
+int vit_load_weight(vit_ctx* ctx, const char* name, const void* src_dev, int src_dtype, int64_t numel,
+                    void* stream);
+/* Number of expected tensors not loaded yet (0 = ready). If `first_missing` is non-NULL
+ * it receives a pointer to the name of one missing tensor (owned by the context). */
+int vit_missing_weights(vit_ctx* ctx, const char** first_missing);
+
+/* Bytes of caller-provided scratch vit_forward needs for `batch` images. */
+size_t vit_workspace_bytes(const vit_ctx* ctx, int batch);
+
+/* Whole encoder forward: ViTModel.forward (MV:356-388) / CLIPVisionModel.forward
+ * (MC:641-656).
+ *   pixels_dev   [batch, C, image, image], dtype pixel_dtype (VIT_F32 or VIT_BF16)
+ *   hidden_out   [batch, N, D] in the context dtype  (last_hidden_state)
+ *   pooled_out   [batch, D]    in the context dtype  (ViT: CLS row of hidden_out;
+ *                CLIP: post_layernorm of the CLS row). May be NULL.
+ *   workspace    >= vit_workspace_bytes(ctx, batch) bytes, 256-byte aligned. */
+int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
+                void* pooled_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-kernel entry points (each unit-testable against oracle/vit_oracle.py) ---- */
+
+/* nn.LayerNorm over the last dim, biased variance, fp32 statistics (MV:261-262,274,281).
+ * x,y: [rows, dim] of `dtype` with the given row strides in elements; gamma,beta: fp32. */
+int vit_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int rows, int dim,
+                      int64_t x_row_stride, int64_t y_row_stride, float eps, int dtype, void* stream);
+
+/* nn.Linear with fused epilogue: C[M,N] = epi(A[M,K] W[N,K]^T + bias[N] (+ residual[M,N])).
+ * A, W, residual, C of `dtype`, row-major contiguous; bias fp32 or NULL. K % 8 == 0 and
+ * N % 8 == 0 (bf16) / K % 4 == 0 and N % 4 == 0 (fp32). (MV:216-218, 236, 250-252) */
+int vit_gemm_bias_act(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,
+                      int N, int K, int epilogue, int dtype, void* stream);
+
+/* Fused multi-head self-attention, softmax(Q K^T * head_dim^-0.5) V with fp32 online
+ * softmax and no materialised score matrix (eager_attention_forward, MV:164-189; no mask,
+ * not causal). qkv: [batch*seq, 3*heads*head_dim] rows laid out q|k|v (the packed QKV GEMM
+ * output); out: [batch*seq, heads*head_dim] (= attn_output after transpose(1,2).reshape,
+ * MV:187,235). head_dim % 16 == 0, head_dim <= 128. */
+int vit_attention_fwd(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, int dtype,
+                      void* stream);
+
+/* Patch embedding as an im2col-free strided GEMM + CLS prepend + position add
+ * (ViTPatchEmbeddings.forward MV:62-69, ViTEmbeddings.forward MV:129-161; CLIP MC:202-218).
+ *   pixels [batch, C, image, image] of `dtype`; weight [D, Kpad] of `dtype` where row d holds
+ *   the Conv2d kernel flattened (c,i,j) and zero-padded to Kpad = vit_patch_kpad(C,P,dtype);
+ *   bias fp32 [D] or NULL; cls fp32 [D]; pos fp32 [N, D]; x_out [batch, N, D] of `dtype`. */
+int vit_patch_embed_fwd(const void* pixels, const void* weight, const float* bias, const float* cls,
+                        const float* pos, void* x_out, int batch, int channels, int image, int patch,
+                        int dim, int dtype, void* stream);
+int vit_patch_kpad(int channels, int patch, int dtype);
+
+/* Elementwise dtype conversion (plumbing for weight / pixel ingestion). */
+int vit_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT_AMD_H */

@@ -1,0 +1,34 @@
+"""Shared test helpers: golden fixtures, configs, error metrics."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+from vit_amd.config import ViTConfig
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    cfg = ViTConfig(**ast.literal_eval(str(z["config_json"])))
+    return cfg, int(z["batch"]), {k: z[k] for k in z.files}
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a-b| / max |b| : the 'relative error' of BASELINE.json's fp32 bar."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def cosine(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm())).item()
+
+
+def min_row_cosine(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    a = a.reshape(-1, a.shape[-1])
+    b = b.reshape(-1, b.shape[-1])
+    return ((a * b).sum(-1) / (a.norm(dim=-1) * b.norm(dim=-1))).min().item()

@@ -1,0 +1,149 @@
+"""GPU parity tests of the whole encoder through vit_forward (C ABI), against the golden
+fixtures (HF transformers outputs) and the oracle.
+
+Bars (BASELINE.json north_star): fp32 mode max-abs / max-abs-ref <= 1e-4; bf16 mode CLS-embedding
+cosine >= 0.999 with the max-abs error printed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle
+from tests.helpers import cosine, load_golden, min_row_cosine, rel_err
+from vit_amd import _lib, synth
+from vit_amd.config import ViTConfig
+from vit_amd.encoder import ViTEncoder
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TINY = ["tiny_vit_p8", "tiny_vit_p14_dh80", "tiny_clip_p14", "tiny_vit_p16_n197"]
+
+
+def build(cfg, dtype):
+    enc = ViTEncoder(cfg, dtype=dtype, device=DEV)
+    enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0))
+    return enc
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_fp32_matches_golden_tiny(name):
+    cfg, batch, fx = load_golden(name)
+    out = build(cfg, torch.float32)(synth.synthetic_images(cfg, batch, seed=1))
+    assert rel_err(out.last_hidden_state, torch.from_numpy(fx["hidden"])) < 1e-4
+    assert rel_err(out.pooler_output, torch.from_numpy(fx["pooled"])) < 1e-4
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_bf16_matches_golden_tiny(name):
+    cfg, batch, fx = load_golden(name)
+    out = build(cfg, torch.bfloat16)(synth.synthetic_images(cfg, batch, seed=1))
+    ref_h, ref_p = torch.from_numpy(fx["hidden"]), torch.from_numpy(fx["pooled"])
+    print(f"{name}: bf16 pooled max-abs {(out.pooler_output.float().cpu() - ref_p).abs().max():.4f}")
+    assert min_row_cosine(out.pooler_output, ref_p) >= 0.999
+    assert min_row_cosine(out.last_hidden_state, ref_h) >= 0.998
+
+
+def test_fp32_matches_golden_vit_b16():
+    cfg, batch, fx = load_golden("vit_b16_224")
+    out = build(cfg, torch.float32)(synth.synthetic_images(cfg, batch, seed=1))
+    assert rel_err(out.pooler_output, torch.from_numpy(fx["pooled"])) < 1e-4
+    rows = out.last_hidden_state[:, :: max(1, cfg.seq_len // 8)]
+    assert rel_err(rows, torch.from_numpy(fx["hidden_rows"])) < 1e-4
+    assert abs(out.last_hidden_state.double().sum().item() - float(fx["hidden_sum"])) < 1e-4 * float(fx["hidden_abs_sum"])
+
+
+def test_bf16_matches_golden_vit_b16():
+    cfg, batch, fx = load_golden("vit_b16_224")
+    out = build(cfg, torch.bfloat16)(synth.synthetic_images(cfg, batch, seed=1).to(torch.bfloat16))
+    ref = torch.from_numpy(fx["pooled"])
+    err = (out.pooler_output.float().cpu() - ref).abs().max().item()
+    cos = min_row_cosine(out.pooler_output, ref)
+    print(f"vit_b16_224 bf16: CLS min cosine {cos:.6f}, max-abs {err:.4f} (ref max {ref.abs().max():.3f})")
+    assert cos >= 0.999
+    assert min_row_cosine(out.last_hidden_state[:, :: max(1, cfg.seq_len // 8)], torch.from_numpy(fx["hidden_rows"])) >= 0.998
+
+
+@pytest.mark.parametrize("name,dtype", [("clip_l14_336", torch.bfloat16), ("clip_l14_336", torch.float32),
+                                        ("vit_h14_448", torch.bfloat16)])
+def test_large_configs_match_golden(name, dtype):
+    cfg, batch, fx = load_golden(name)
+    out = build(cfg, dtype)(synth.synthetic_images(cfg, batch, seed=1))
+    ref = torch.from_numpy(fx["pooled"])
+    if dtype == torch.float32:
+        assert rel_err(out.pooler_output, ref) < 1e-4
+        assert rel_err(out.last_hidden_state[:, :: max(1, cfg.seq_len // 8)], torch.from_numpy(fx["hidden_rows"])) < 1e-4
+    else:
+        err = (out.pooler_output.float().cpu() - ref).abs().max().item()
+        print(f"{name} bf16: CLS min cosine {min_row_cosine(out.pooler_output, ref):.6f}, max-abs {err:.4f}")
+        assert min_row_cosine(out.pooler_output, ref) >= 0.999
+
+
+def test_full_batch_properties_vit_b16_bf16():
+    """BASELINE.json configs[1] size (batch 256): size-independent properties.
+    Images are independent, so (a) a permuted batch gives the permuted output bit-exactly,
+    (b) a sub-batch gives the same rows bit-exactly, (c) every embedding is finite and a
+    sample of rows matches the CPU oracle."""
+    cfg = ViTConfig.vit_b16_224()
+    enc = build(cfg, torch.bfloat16)
+    px = synth.synthetic_images(cfg, 256, seed=2, device=DEV).to(torch.bfloat16)
+    out = enc(px)
+    assert torch.isfinite(out.last_hidden_state).all()
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(0)).to(DEV)
+    out_p = enc(px[perm])
+    assert torch.equal(out_p.pooler_output, out.pooler_output[perm])
+    assert torch.equal(out_p.last_hidden_state, out.last_hidden_state[perm])
+    out_s = enc(px[100:108])
+    assert torch.equal(out_s.last_hidden_state, out.last_hidden_state[100:108])
+    sd = vit_oracle.quantize_state_dict_bf16(synth.synthetic_state_dict(cfg, seed=0))
+    idx = [0, 101, 255]
+    _, ref = vit_oracle.forward(px[idx].float().cpu(), sd, cfg)
+    assert min_row_cosine(out.pooler_output[idx], ref) >= 0.999
+
+
+def test_hf_prefixes_and_bf16_sources_accepted():
+    cfg, batch, fx = load_golden("tiny_vit_p8")
+    sd = {"vit." + k: v.to(torch.bfloat16) for k, v in synth.synthetic_state_dict(cfg, seed=0).items()}
+    enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
+    enc.load_state_dict(sd)
+    out = enc(synth.synthetic_images(cfg, batch, seed=1))
+    assert min_row_cosine(out.pooler_output, torch.from_numpy(fx["pooled"])) >= 0.999
+
+
+def test_error_behaviour():
+    cfg, batch, _ = load_golden("tiny_vit_p8")
+    enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
+    px = synth.synthetic_images(cfg, batch, seed=1)
+    with pytest.raises(_lib.VitError, match="not loaded"):
+        enc(px)                                                   # weights missing
+    sd = synth.synthetic_state_dict(cfg, seed=0)
+    with pytest.raises(_lib.VitError, match="unexpected key"):
+        enc.load_state_dict({**sd, "bogus.weight": torch.zeros(3)})
+    with pytest.raises(_lib.VitError, match="elements"):
+        enc.load_state_dict({"layernorm.weight": torch.zeros(3)})
+    missing = dict(sd)
+    missing.pop("layernorm.bias")
+    with pytest.raises(KeyError):
+        ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV).load_state_dict(missing)
+    enc.load_state_dict(sd)
+    with pytest.raises(ValueError, match="channel dimension"):
+        enc(torch.zeros(1, 1, 32, 32))
+    with pytest.raises(ValueError, match="doesn't match model"):
+        enc(torch.zeros(1, 3, 40, 40))
+    empty = enc(torch.zeros(0, 3, 32, 32))
+    assert tuple(empty.last_hidden_state.shape) == (0, cfg.seq_len, cfg.hidden_size)
+    # too-small workspace is refused by the library itself
+    lib = _lib.load()
+    ws = torch.empty(256, dtype=torch.uint8, device=DEV)
+    h = torch.empty(batch, cfg.seq_len, cfg.hidden_size, dtype=torch.bfloat16, device=DEV)
+    rc = lib.vit_forward(enc._ctx, px.to(DEV).data_ptr(), _lib.VIT_F32, batch, h.data_ptr(), None, ws.data_ptr(), 256,
+                         None)
+    assert rc == -4 and b"workspace" in lib.vit_last_error()
+
+
+def test_determinism_repeat_runs():
+    cfg, batch, _ = load_golden("tiny_vit_p16_n197")
+    enc = build(cfg, torch.bfloat16)
+    px = synth.synthetic_images(cfg, batch, seed=1)
+    a = enc(px).last_hidden_state.clone()
+    for _ in range(3):
+        assert torch.equal(enc(px).last_hidden_state, a)

@@ -1,0 +1,192 @@
+"""GPU parity tests, per kernel, through the C ABI, against oracle/vit_oracle.py.
+
+Tolerances. fp32 mode: max-abs error / max-abs reference <= 1e-4 (BASELINE.json's fp32 bar).
+bf16 mode: inputs are rounded to bf16 first and the oracle runs on the ROUNDED inputs, so what
+is measured is the kernel's arithmetic (fp32 accumulate, one bf16 rounding of the output):
+bound 2^-8 relative to the output scale plus accumulated-input noise, stated per test.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import vit_oracle
+from tests.helpers import rel_err, min_row_cosine
+from vit_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF16_TOL = 1.0 / 128  # 2 bf16 ulps of the output scale
+
+
+def rnd(shape, name, std=1.0, seed=7):
+    return synth.normal(shape, seed, name, std=std)
+
+
+def q(t):  # what a bf16 kernel actually sees
+    return t.to(torch.bfloat16).float()
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,dim", [(1, 64), (5, 160), (197, 768), (1000, 1024), (77, 1280), (3, 2048), (9, 4)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("eps", [1e-12, 1e-5])
+def test_layernorm(rows, dim, dtype, eps):
+    x = rnd((rows, dim), "ln.x") * 3 + 0.5
+    w, b = rnd((dim,), "ln.w", 0.1) + 1, rnd((dim,), "ln.b", 0.1)
+    if dtype == torch.bfloat16:
+        x = q(x)
+    ref = vit_oracle.layer_norm(x, w, b, eps)
+    out = ops.layer_norm(x.to(DEV, dtype), w.to(DEV), b.to(DEV), eps)
+    assert out.dtype == dtype and out.shape == ref.shape
+    assert rel_err(out, ref) < (1e-5 if dtype == torch.float32 else BF16_TOL)
+
+
+def test_layernorm_constant_rows_and_3d_input():
+    # zero variance with eps=1e-12 (ViT's eps): output must be exactly beta, not NaN
+    x = torch.full((2, 3, 768), 2.5)
+    w, b = rnd((768,), "w") + 1, rnd((768,), "b")
+    out = ops.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-12)
+    assert torch.isfinite(out).all()
+    assert rel_err(out, b.expand(2, 3, 768)) < 1e-6
+
+
+# ------------------------------------------------------------------ GEMM + epilogues
+GEMM_SHAPES = [
+    (1, 8, 8), (17, 64, 64), (51, 192, 64), (20, 320, 160), (20, 160, 320),  # tiny / ragged K (160 % 64 != 0)
+    (394, 768, 768), (394, 2304, 768), (300, 768, 3072), (513, 3072, 768),   # ViT-B layer shapes, ragged M
+    (256, 128, 64), (257, 136, 72),                                        # BN=128 path, N not multiple of tile
+]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("epi", ["none", "gelu", "quick_gelu", "residual", "nobias"])
+def test_linear(m, n, k, dtype, epi):
+    x, w = rnd((m, k), "g.x"), rnd((n, k), "g.w", 1 / math.sqrt(k))
+    bias = None if epi == "nobias" else rnd((n,), "g.b", 0.5)
+    res = rnd((m, n), "g.r") if epi == "residual" else None
+    if dtype == torch.bfloat16:
+        x, w = q(x), q(w)
+        res = None if res is None else q(res)
+    ref = x @ w.t()
+    if bias is not None:
+        ref = ref + bias
+    if epi in ("gelu", "quick_gelu"):
+        ref = vit_oracle.activation(ref, epi)
+    if res is not None:
+        ref = ref + res
+    out = ops.linear(x.to(DEV, dtype), w.to(DEV, dtype), None if bias is None else bias.to(DEV),
+                     activation=epi if epi in ("gelu", "quick_gelu") else None,
+                     residual=None if res is None else res.to(DEV, dtype))
+    assert out.dtype == dtype and tuple(out.shape) == (m, n)
+    assert rel_err(out, ref) < (1e-5 if dtype == torch.float32 else BF16_TOL)
+
+
+def test_linear_identity_asymmetric():
+    # A = I with an asymmetric W catches transposed / permuted output maps exactly
+    n = 256
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 125.0   # exact in bf16
+    eye = torch.eye(n)
+    for dtype in (torch.float32, torch.bfloat16):
+        out = ops.linear(eye.to(DEV, dtype), w.to(DEV, dtype))
+        assert torch.equal(out.float().cpu(), w.t())
+
+
+def test_linear_residual_in_place_semantics():
+    # the encoder calls the residual epilogue with C aliasing the residual
+    from vit_amd import _lib
+    m, n, k = 300, 768, 768
+    x, w, r = q(rnd((m, k), "x")), q(rnd((n, k), "w", 0.03)), q(rnd((m, n), "r"))
+    xd, wd, rd = x.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), r.to(DEV, torch.bfloat16)
+    _lib.check(_lib.load().vit_gemm_bias_act(xd.data_ptr(), wd.data_ptr(), None, rd.data_ptr(), rd.data_ptr(), m, n, k,
+                                             _lib.EPI_RESIDUAL, _lib.VIT_BF16, torch.cuda.current_stream().cuda_stream))
+    assert rel_err(rd, x @ w.t() + r) < BF16_TOL
+
+
+def test_linear_rejects_bad_shapes():
+    from vit_amd import _lib
+    x = torch.zeros(4, 12, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(8, 12, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_lib.VitError):
+        ops.linear(x, w)  # K % 8 != 0 in bf16
+    with pytest.raises(ValueError):
+        ops.linear(x, torch.zeros(8, 16, device=DEV, dtype=torch.bfloat16))
+
+
+# ------------------------------------------------------------------ attention
+ATTN_CASES = [  # batch, seq, heads, head_dim
+    (2, 10, 2, 80), (3, 17, 4, 16), (2, 197, 12, 64), (1, 577, 4, 64), (1, 1025, 2, 80), (2, 33, 2, 128),
+    (1, 1, 1, 32), (2, 32, 3, 64), (1, 225, 2, 64), (1, 300, 1, 48),
+]
+
+
+def ref_attention(qkv, heads):
+    b, n, d3 = qkv.shape
+    d = d3 // 3
+    dh = d // heads
+    qh, kh, vh = [t.reshape(b, n, heads, dh).transpose(1, 2) for t in qkv.split(d, dim=-1)]
+    p = torch.softmax((qh @ kh.transpose(2, 3)) * dh ** -0.5, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(b, n, d)
+
+
+@pytest.mark.parametrize("b,n,h,dh", ATTN_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention(b, n, h, dh, dtype):
+    qkv = rnd((b, n, 3 * h * dh), "a.qkv", 1.5)
+    if dtype == torch.bfloat16:
+        qkv = q(qkv)
+    ref = ref_attention(qkv, h)
+    out = ops.attention(qkv.to(DEV, dtype), h)
+    assert out.dtype == dtype and out.shape == ref.shape
+    # bf16: P is rounded to bf16 before PV (as torch's .to(query.dtype) does, modeling_vit.py:183)
+    assert rel_err(out, ref) < (2e-5 if dtype == torch.float32 else 2 * BF16_TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_online_softmax_rescale_branch(dtype):
+    # Force the running max to jump at a LATER key tile/chunk (a spiked K row far into the
+    # sequence): exercises the rescale of O and l, which bounded random data rarely does.
+    b, n, h, dh = 1, 577, 2, 64
+    qkv = rnd((b, n, 3 * h * dh), "spike", 0.5)
+    qkv[0, 500, h * dh: 2 * h * dh] *= 25.0   # key 500 of both heads (3rd LDS chunk)
+    qkv[0, 70, h * dh: 2 * h * dh] *= 12.0    # and a smaller one in tile 2
+    if dtype == torch.bfloat16:
+        qkv = q(qkv)
+    ref = ref_attention(qkv, h)
+    out = ops.attention(qkv.to(DEV, dtype), h)
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < (2e-5 if dtype == torch.float32 else 2 * BF16_TOL)
+
+
+def test_attention_uniform_scores_average_values():
+    # q = 0 -> uniform softmax -> every output row is the mean of V (exact property)
+    b, n, h, dh = 2, 197, 3, 64
+    qkv = rnd((b, n, 3 * h * dh), "u")
+    qkv[..., : h * dh] = 0
+    out = ops.attention(qkv.to(DEV), h)
+    mean_v = qkv[..., 2 * h * dh:].mean(dim=1, keepdim=True).expand(b, n, h * dh)
+    assert rel_err(out, mean_v) < 1e-5
+
+
+# ------------------------------------------------------------------ patch embedding
+@pytest.mark.parametrize("b,c,img,p,d", [(3, 3, 32, 8, 64), (2, 3, 42, 14, 160), (2, 3, 224, 16, 128),
+                                          (1, 3, 336, 14, 64), (2, 1, 30, 5, 32), (5, 3, 224, 16, 768)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_patch_embed(b, c, img, p, d, dtype, with_bias):
+    if dtype == torch.bfloat16 and d % 8:
+        pytest.skip("bf16 needs D % 8 == 0")
+    n = (img // p) ** 2 + 1
+    px, w = rnd((b, c, img, img), "p.x"), rnd((d, c, p, p), "p.w", 0.05)
+    bias = rnd((d,), "p.b", 0.3) if with_bias else None
+    cls, pos = rnd((1, 1, d), "p.cls"), rnd((1, n, d), "p.pos")
+    if dtype == torch.bfloat16:
+        px, w = q(px), q(w)
+    pe = vit_oracle.patch_embed(px, w, bias, p)
+    ref = torch.cat([cls.expand(b, 1, d), pe], dim=1) + pos
+    out = ops.patch_embed(px.to(DEV, dtype), w.to(DEV, dtype), None if bias is None else bias.to(DEV), cls.to(DEV),
+                          pos.to(DEV), p)
+    assert tuple(out.shape) == (b, n, d)
+    assert rel_err(out, ref) < (1e-5 if dtype == torch.float32 else BF16_TOL)
+    assert min_row_cosine(out, ref) > 0.9999

@@ -1,0 +1,106 @@
+"""CPU: host logic -- config, synthetic generator, C-ABI library surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from vit_amd import _lib, synth
+from vit_amd.config import ViTConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flops_match_survey():
+    # SURVEY.md section 8d / BASELINE.md
+    assert ViTConfig.vit_b16_224().flops_per_image() == 35_126_120_448
+    assert ViTConfig.clip_l14_336().flops_per_image() == 381_918_216_192
+    assert ViTConfig.vit_h14_448().flops_per_image() == 1_463_424_286_720
+
+
+def test_config_shapes_and_validation():
+    c = ViTConfig.vit_b16_224()
+    assert (c.seq_len, c.head_dim, c.patch_dim) == (197, 64, 768)
+    c = ViTConfig.vit_h14_448()
+    assert (c.seq_len, c.head_dim, c.patch_dim) == (1025, 80, 588)
+    with pytest.raises(ValueError):
+        ViTConfig(hidden_size=100, num_attention_heads=3)
+    with pytest.raises(ValueError):
+        ViTConfig(image_size=225)
+    with pytest.raises(ValueError):
+        ViTConfig(hidden_act="relu")
+
+
+def test_state_dict_key_counts():
+    # ViT-B has 198 keys / 85,798,656 params; CLIP-L/14-336 303,507,456
+    shapes = synth.state_dict_shapes(ViTConfig.vit_b16_224())
+    assert len(shapes) == 198
+    assert sum(int(torch.Size(s).numel()) for s in shapes.values()) == 85_798_656
+    shapes = synth.state_dict_shapes(ViTConfig.clip_l14_336())
+    assert sum(int(torch.Size(s).numel()) for s in shapes.values()) == 303_507_456
+
+
+def test_synth_is_counter_based():
+    a = synth.normal((1000,), 3, "w")
+    b = synth.normal((1000,), 3, "w", chunk=128)  # chunking must not change values
+    assert torch.equal(a, b)
+    assert not torch.equal(a, synth.normal((1000,), 4, "w"))
+    assert not torch.equal(a, synth.normal((1000,), 3, "v"))
+    big = synth.normal((200_000,), 0, "x")
+    assert abs(big.mean().item()) < 0.01 and abs(big.std().item() - 1.0) < 0.01
+    # pinned values: any change to the generator invalidates every golden fixture
+    assert [round(v, 6) for v in synth.normal((3,), 0, "pin").tolist()] == \
+        [round(v, 6) for v in torch.tensor(PINNED).tolist()]
+
+
+PINNED = [0.915923535823822, -2.1585094928741455, -0.8343636393547058]
+
+
+def test_synthetic_weights_have_nontrivial_bias_and_affine():
+    sd = synth.synthetic_state_dict(ViTConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=4,
+                                              intermediate_size=128, image_size=32, patch_size=8))
+    assert sd["layers.0.attention.q_proj.bias"].abs().max() > 0.01
+    assert (sd["layers.0.layernorm_before.weight"] - 1).abs().max() > 0.01
+    assert sd["layernorm.bias"].abs().max() > 0.01
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "vit_amd.h")).read()
+    declared = set(re.findall(r"\b(vit_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vit_ctx", "vit_config"}
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = _lib.load()  # raises if the .so or any symbol is missing
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.vit_abi_version() == 1
+
+
+def test_argument_errors_need_no_gpu():
+    lib = _lib.load()
+    assert lib.vit_create(None, None) == -1
+    assert b"null" in lib.vit_last_error()
+    cfg = _lib.vit_config(hidden_size=100, num_hidden_layers=1, num_attention_heads=3, intermediate_size=8,
+                          image_size=32, patch_size=8, num_channels=3, hidden_act=0, variant=0, qkv_bias=1, dtype=1,
+                          layer_norm_eps=1e-12)
+    h = ctypes.c_void_p()
+    assert lib.vit_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"num_attention_heads" in lib.vit_last_error()
+    with pytest.raises(_lib.VitError):
+        _lib.check(lib.vit_gemm_bias_act(None, None, None, None, None, 1, 1, 1, 0, 1, None))
+    assert lib.vit_patch_kpad(3, 14, _lib.VIT_BF16) == 592
+    assert lib.vit_patch_kpad(3, 14, _lib.VIT_F32) == 588
+    assert lib.vit_patch_kpad(3, 16, _lib.VIT_BF16) == 768
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libvit_amd.so")
+    with pytest.raises(_lib.VitLibraryError):
+        _lib.load()
+
+
+def test_encoder_refuses_cpu():
+    from vit_amd.encoder import ViTEncoder
+    with pytest.raises(ValueError):
+        ViTEncoder(ViTConfig(), device="cpu")

@@ -1,0 +1,87 @@
+"""ctypes binding of libvit_amd.so (the C ABI of include/vit_amd.h).
+
+There is NO fallback: if the shared library is missing or lacks a symbol, import of the
+ops fails loudly (``VitLibraryError``). torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER, Structure
+
+VIT_F32, VIT_BF16 = 0, 1
+EPI_BIAS, EPI_GELU, EPI_QUICK_GELU, EPI_RESIDUAL = 0, 1, 2, 3
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvit_amd.so")
+
+
+class VitLibraryError(RuntimeError):
+    pass
+
+
+class VitError(RuntimeError):
+    """A C-ABI call returned a negative VIT_E_* code."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libvit_amd error {code}: {msg}")
+        self.code = code
+
+
+class vit_config(Structure):
+    _fields_ = [("hidden_size", c_int32), ("num_hidden_layers", c_int32), ("num_attention_heads", c_int32),
+                ("intermediate_size", c_int32), ("image_size", c_int32), ("patch_size", c_int32),
+                ("num_channels", c_int32), ("hidden_act", c_int32), ("variant", c_int32), ("qkv_bias", c_int32),
+                ("dtype", c_int32), ("layer_norm_eps", c_float)]
+
+
+# name -> (restype, argtypes): every symbol include/vit_amd.h declares
+SIGNATURES = {
+    "vit_last_error": (c_char_p, []),
+    "vit_abi_version": (c_int, []),
+    "vit_create": (c_int, [POINTER(vit_config), POINTER(c_void_p)]),
+    "vit_destroy": (c_int, [c_void_p]),
+    "vit_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int64, c_void_p]),
+    "vit_missing_weights": (c_int, [c_void_p, POINTER(c_char_p)]),
+    "vit_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_float,
+                                  c_int, c_void_p]),
+    "vit_gemm_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_void_p]),
+    "vit_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vit_patch_embed_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p]),
+    "vit_patch_kpad": (c_int, [c_int, c_int, c_int]),
+    "vit_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once and bind every declared symbol; raise if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C vit_amd/csrc` (or __graft_entry__.build()). "
+            "vit_amd has no CPU or eager fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise VitLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VitLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise VitError(rc, load().vit_last_error().decode(errors="replace"))

@@ -1,0 +1,208 @@
+// LayerNorm forward: y = (x - mean) / sqrt(var + eps) * gamma + beta, biased variance,
+// fp32 statistics (nn.LayerNorm as used at modeling_vit.py:261-262,274,281,385 and
+// modeling_clip.py:605,607). HBM-bound: one wavefront per row, the row lives in registers
+// between the load and the store (read once, write once), 8/16-byte coalesced accesses,
+// mean and centred variance by two in-register passes + a 64-lane butterfly reduction.
+// Also the small elementwise kernels of the path (dtype convert, CLS rows).
+#include "vit_common.h"
+
+namespace {
+
+template <typename T>
+struct Vec4;  // 4 elements of T as one coalesced access
+template <>
+struct Vec4<float> {
+    __device__ static f32x4 load(const float* p) { return *(const f32x4*)p; }
+    __device__ static void store(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <>
+struct Vec4<bf16_t> {
+    __device__ static f32x4 load(const bf16_t* p) {
+        const bf16x4 t = *(const bf16x4*)p;
+        return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    }
+    __device__ static void store(bf16_t* p, f32x4 v) {
+        bf16x4 t;
+        t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+        *(bf16x4*)p = t;
+    }
+};
+
+// NIT = ceil(dim / 256): register-resident row, 4 elements per lane per iteration.
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y, int rows,
+                                                        int dim, int64_t xs, int64_t ys, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const float inv_d = 1.0f / (float)dim;
+    for (int row = wave_in_grid; row < rows; row += nwaves) {
+        const T* xr = x + (size_t)row * xs;
+        f32x4 v[NIT];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < dim) {
+                v[it] = Vec4<T>::load(xr + c);
+                s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+            } else {
+                v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float ss = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < dim) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[it][e] - mean;
+                    ss += d * d;
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_d + eps);
+        T* yr = y + (size_t)row * ys;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < dim) {
+                const f32x4 g = *(const f32x4*)(gamma + c);
+                const f32x4 b = *(const f32x4*)(beta + c);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + b[e];
+                Vec4<T>::store(yr + c, o);
+            }
+        }
+    }
+}
+
+template <typename T, int NIT>
+int launch_ln_t(const void* x, const float* g, const float* b, void* y, int rows, int dim, int64_t xs, int64_t ys,
+                float eps, hipStream_t stream) {
+    int blocks = ceil_div(rows, 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 blocks per CU
+    hipLaunchKernelGGL((layernorm_kernel<T, NIT>), dim3(blocks), dim3(256), 0, stream, (const T*)x, g, b, (T*)y, rows,
+                       dim, xs, ys, eps);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+template <typename T>
+int launch_ln_nit(const void* x, const float* g, const float* b, void* y, int rows, int dim, int64_t xs, int64_t ys,
+                  float eps, hipStream_t stream) {
+    switch (ceil_div(dim, 256)) {
+        case 1: return launch_ln_t<T, 1>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+        case 2: return launch_ln_t<T, 2>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+        case 3: return launch_ln_t<T, 3>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+        case 4: return launch_ln_t<T, 4>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+        case 5: return launch_ln_t<T, 5>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+        case 6: return launch_ln_t<T, 6>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+        case 7: return launch_ln_t<T, 7>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+        case 8: return launch_ln_t<T, 8>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+    }
+    return vit_set_error(VIT_E_INVALID, "layernorm: dim %d > 2048 unsupported", dim);
+}
+
+// ---- elementwise: dtype convert ----
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            Vec4<D>::store(dst + i, Vec4<S>::load(src + i));
+        } else {
+            for (int64_t j = i; j < n; ++j) dst[j] = (D)(float)src[j];
+        }
+    }
+}
+
+template <typename S, typename D>
+int launch_convert_t(const void* src, void* dst, int64_t n, hipStream_t stream) {
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((convert_kernel<S, D>), dim3((int)blocks), dim3(256), 0, stream, (const S*)src, (D*)dst, n);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+// ---- pitched convert (weight ingestion: rows of `cols` elements into rows of `pitch`) ----
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_2d_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t rows,
+                                                         int64_t cols, int64_t pitch) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols;
+        dst[r * pitch + c] = (D)(float)src[i];
+    }
+}
+
+template <typename S, typename D>
+int launch_convert_2d_t(const void* src, void* dst, int64_t rows, int64_t cols, int64_t pitch, hipStream_t stream) {
+    int64_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((convert_2d_kernel<S, D>), dim3((int)blocks), dim3(256), 0, stream, (const S*)src, (D*)dst, rows,
+                       cols, pitch);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+// ---- CLS rows: x[b, 0, :] = cls + pos[0]  (ViTEmbeddings.forward, modeling_vit.py:147-158) ----
+template <typename T>
+__global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                                       T* __restrict__ x, int batch, int seq, int dim) {
+    const int total = batch * dim;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / dim, d = i - b * dim;
+        x[(size_t)b * seq * dim + d] = (T)(cls[d] + pos[d]);
+    }
+}
+
+}  // namespace
+
+int launch_layernorm(const void* x, const float* g, const float* b, void* y, int rows, int dim, int64_t xs, int64_t ys,
+                     float eps, int dtype, hipStream_t stream) {
+    VIT_REQUIRE(rows > 0 && dim > 0, "layernorm: empty input rows=%d dim=%d", rows, dim);
+    VIT_REQUIRE(dim % 4 == 0 && xs % 4 == 0 && ys % 4 == 0, "layernorm: dim and row strides must be multiples of 4");
+    if (dtype == VIT_BF16) return launch_ln_nit<bf16_t>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+    if (dtype == VIT_F32) return launch_ln_nit<float>(x, g, b, y, rows, dim, xs, ys, eps, stream);
+    return vit_set_error(VIT_E_INVALID, "layernorm: bad dtype %d", dtype);
+}
+
+int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t stream) {
+    VIT_REQUIRE(n >= 0, "convert: negative size");
+    if (n == 0) return VIT_OK;
+    if (sdt == VIT_F32 && ddt == VIT_BF16) return launch_convert_t<float, bf16_t>(src, dst, n, stream);
+    if (sdt == VIT_BF16 && ddt == VIT_F32) return launch_convert_t<bf16_t, float>(src, dst, n, stream);
+    if (sdt == ddt && (sdt == VIT_F32 || sdt == VIT_BF16)) {
+        VIT_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * (sdt == VIT_F32 ? 4 : 2), hipMemcpyDeviceToDevice, stream));
+        return VIT_OK;
+    }
+    return vit_set_error(VIT_E_INVALID, "convert: bad dtypes %d -> %d", sdt, ddt);
+}
+
+int launch_cls_rows(const float* cls, const float* pos, void* x, int batch, int seq, int dim, int dtype,
+                    hipStream_t stream) {
+    const int blocks = ceil_div(batch * dim, 256);
+    if (dtype == VIT_BF16)
+        hipLaunchKernelGGL(cls_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, cls, pos, (bf16_t*)x, batch, seq, dim);
+    else
+        hipLaunchKernelGGL(cls_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, cls, pos, (float*)x, batch, seq, dim);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+int launch_convert_2d(const void* src, int sdt, void* dst, int ddt, int64_t rows, int64_t cols, int64_t dst_pitch,
+                      hipStream_t stream) {
+    VIT_REQUIRE(rows > 0 && cols > 0 && dst_pitch >= cols, "convert_2d: bad shape");
+    if (sdt == VIT_F32 && ddt == VIT_BF16) return launch_convert_2d_t<float, bf16_t>(src, dst, rows, cols, dst_pitch, stream);
+    if (sdt == VIT_BF16 && ddt == VIT_F32) return launch_convert_2d_t<bf16_t, float>(src, dst, rows, cols, dst_pitch, stream);
+    if (sdt == VIT_F32 && ddt == VIT_F32) return launch_convert_2d_t<float, float>(src, dst, rows, cols, dst_pitch, stream);
+    if (sdt == VIT_BF16 && ddt == VIT_BF16) return launch_convert_2d_t<bf16_t, bf16_t>(src, dst, rows, cols, dst_pitch, stream);
+    return vit_set_error(VIT_E_INVALID, "convert_2d: bad dtypes %d -> %d", sdt, ddt);
+}

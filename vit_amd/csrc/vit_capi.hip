@@ -1,0 +1,415 @@
+// C ABI of libvit_amd.so (declared in include/vit_amd.h): context / weight arena, the whole
+// encoder forward (ViTModel.forward modeling_vit.py:356-388, CLIPVisionModel.forward
+// modeling_clip.py:641-656) as a fixed sequence of kernel launches on the caller's stream,
+// and thin argument-checking wrappers around the individual kernels.
+#include "vit_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+int launch_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
+                     int epi, const PatchGeom* patch, const float* pos, hipStream_t stream);
+int launch_gemm_f32(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
+                    int epi, const PatchGeom* patch, const float* pos, hipStream_t stream);
+int launch_convert_2d(const void* src, int sdt, void* dst, int ddt, int64_t rows, int64_t cols, int64_t dst_pitch,
+                      hipStream_t stream);
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+int vit_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int launch_gemm(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K, int epi,
+                int dtype, const PatchGeom* patch, const float* pos, hipStream_t stream) {
+    if (dtype == VIT_BF16) return launch_gemm_bf16(A, W, bias, res, C, M, N, K, epi, patch, pos, stream);
+    if (dtype == VIT_F32) return launch_gemm_f32(A, W, bias, res, C, M, N, K, epi, patch, pos, stream);
+    return vit_set_error(VIT_E_INVALID, "gemm: bad dtype %d", dtype);
+}
+
+// ---------------------------------------------------------------- context
+namespace {
+
+struct Slot {
+    size_t offset;      // bytes into the arena
+    int64_t rows, cols; // source shape as a matrix (vectors: rows = 1)
+    int64_t pitch;      // destination row pitch in elements
+    int dtype;          // storage dtype in the arena
+    bool loaded;
+};
+
+struct LayerW {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
+    void *wqkv, *wo, *w1, *w2;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline size_t esize(int dt) { return dt == VIT_F32 ? 4 : 2; }
+
+}  // namespace
+
+struct vit_ctx {
+    vit_config cfg;
+    int device;
+    int N, dh, kreal, kpad;
+    unsigned char* arena;
+    size_t arena_bytes;
+    std::map<std::string, Slot> slots;
+    std::vector<std::string> optional;  // names that may legitimately stay unloaded (none today)
+    std::string missing_name;
+    int n_missing;
+    // resolved pointers
+    void* patch_w;
+    float *patch_b, *cls, *pos, *pre_g, *pre_b, *fin_g, *fin_b;
+    std::vector<LayerW> layers;
+};
+
+namespace {
+
+struct ArenaBuilder {
+    size_t cur = 0;
+    std::map<std::string, Slot>* slots;
+    size_t add(const std::string& name, int64_t rows, int64_t cols, int64_t pitch, int dtype) {
+        const size_t off = cur;
+        (*slots)[name] = Slot{off, rows, cols, pitch, dtype, false};
+        cur = align256(cur + (size_t)rows * pitch * esize(dtype));
+        return off;
+    }
+    size_t raw(size_t bytes) {  // unnamed zero-initialised region
+        const size_t off = cur;
+        cur = align256(cur + bytes);
+        return off;
+    }
+};
+
+}  // namespace
+
+extern "C" const char* vit_last_error(void) { return g_err; }
+extern "C" int vit_abi_version(void) { return 1; }
+
+extern "C" int vit_patch_kpad(int channels, int patch, int dtype) {
+    const int k = channels * patch * patch;
+    return dtype == VIT_BF16 ? (k + 7) / 8 * 8 : k;
+}
+
+extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
+    VIT_REQUIRE(cfg != nullptr && out != nullptr, "vit_create: null argument");
+    *out = nullptr;
+    const vit_config& c = *cfg;
+    VIT_REQUIRE(c.dtype == VIT_F32 || c.dtype == VIT_BF16, "vit_create: dtype must be VIT_F32 or VIT_BF16");
+    VIT_REQUIRE(c.variant == VIT_VARIANT_VIT || c.variant == VIT_VARIANT_CLIP, "vit_create: bad variant %d", c.variant);
+    VIT_REQUIRE(c.hidden_act == VIT_ACT_GELU || c.hidden_act == VIT_ACT_QUICK_GELU, "vit_create: bad hidden_act");
+    VIT_REQUIRE(c.hidden_size > 0 && c.num_hidden_layers > 0 && c.num_attention_heads > 0 && c.intermediate_size > 0,
+                "vit_create: non-positive size");
+    VIT_REQUIRE(c.hidden_size % c.num_attention_heads == 0, "vit_create: hidden_size %% num_attention_heads != 0");
+    VIT_REQUIRE(c.patch_size > 0 && c.image_size % c.patch_size == 0, "vit_create: image_size %% patch_size != 0");
+    VIT_REQUIRE(c.num_channels > 0, "vit_create: num_channels must be positive");
+    const int dh = c.hidden_size / c.num_attention_heads;
+    VIT_REQUIRE(dh % 16 == 0 && dh <= 128, "vit_create: head_dim %d unsupported (multiple of 16, <= 128)", dh);
+    VIT_REQUIRE(c.hidden_size % 8 == 0 && c.intermediate_size % 8 == 0, "vit_create: D and F must be multiples of 8");
+    VIT_REQUIRE(c.hidden_size <= 2048, "vit_create: hidden_size > 2048 unsupported by the LayerNorm kernel");
+
+    vit_ctx* ctx = new vit_ctx();
+    ctx->cfg = c;
+    VIT_CHECK_HIP(hipGetDevice(&ctx->device));
+    const int D = c.hidden_size, F = c.intermediate_size, L = c.num_hidden_layers;
+    const int g = c.image_size / c.patch_size;
+    ctx->N = g * g + 1;
+    ctx->dh = dh;
+    ctx->kreal = c.num_channels * c.patch_size * c.patch_size;
+    ctx->kpad = vit_patch_kpad(c.num_channels, c.patch_size, c.dtype);
+    const int T = c.dtype;
+    const bool clip = c.variant == VIT_VARIANT_CLIP;
+
+    ArenaBuilder ab;
+    ab.slots = &ctx->slots;
+    struct LayerOff { size_t ln1g, ln1b, ln2g, ln2b, bqkv, bo, b1, b2, wqkv, wo, w1, w2; };
+    std::vector<LayerOff> lo(L);
+    size_t o_patch_w, o_patch_b, o_cls, o_pos, o_pre_g = 0, o_pre_b = 0, o_fin_g, o_fin_b;
+
+    if (!clip) {
+        o_cls = ab.add("embeddings.cls_token", 1, D, D, VIT_F32);
+        o_pos = ab.add("embeddings.position_embeddings", 1, (int64_t)ctx->N * D, (int64_t)ctx->N * D, VIT_F32);
+        o_patch_w = ab.add("embeddings.patch_embeddings.projection.weight", D, ctx->kreal, ctx->kpad, T);
+        o_patch_b = ab.add("embeddings.patch_embeddings.projection.bias", 1, D, D, VIT_F32);
+    } else {
+        o_cls = ab.add("embeddings.class_embedding", 1, D, D, VIT_F32);
+        o_pos = ab.add("embeddings.position_embedding.weight", 1, (int64_t)ctx->N * D, (int64_t)ctx->N * D, VIT_F32);
+        o_patch_w = ab.add("embeddings.patch_embedding.weight", D, ctx->kreal, ctx->kpad, T);
+        o_patch_b = ab.raw((size_t)D * 4);  // Conv2d(bias=False), modeling_clip.py:148-154
+        o_pre_g = ab.add("pre_layrnorm.weight", 1, D, D, VIT_F32);
+        o_pre_b = ab.add("pre_layrnorm.bias", 1, D, D, VIT_F32);
+    }
+    for (int l = 0; l < L; ++l) {
+        char p[96];
+        const char *ln1, *ln2, *q, *k, *v, *o;
+        if (!clip) {
+            snprintf(p, sizeof(p), "layers.%d.", l);
+            ln1 = "layernorm_before"; ln2 = "layernorm_after";
+            q = "attention.q_proj"; k = "attention.k_proj"; v = "attention.v_proj"; o = "attention.o_proj";
+        } else {
+            snprintf(p, sizeof(p), "encoder.layers.%d.", l);
+            ln1 = "layer_norm1"; ln2 = "layer_norm2";
+            q = "self_attn.q_proj"; k = "self_attn.k_proj"; v = "self_attn.v_proj"; o = "self_attn.out_proj";
+        }
+        const std::string pre(p);
+        lo[l].ln1g = ab.add(pre + ln1 + ".weight", 1, D, D, VIT_F32);
+        lo[l].ln1b = ab.add(pre + ln1 + ".bias", 1, D, D, VIT_F32);
+        lo[l].ln2g = ab.add(pre + ln2 + ".weight", 1, D, D, VIT_F32);
+        lo[l].ln2b = ab.add(pre + ln2 + ".bias", 1, D, D, VIT_F32);
+        // packed [3D, D] QKV: three slots into one matrix / one bias vector
+        lo[l].wqkv = ab.cur;
+        const bool has_qkv_bias = clip || c.qkv_bias;
+        const char* names[3] = {q, k, v};
+        for (int j = 0; j < 3; ++j) {
+            (*ab.slots)[pre + names[j] + ".weight"] =
+                Slot{lo[l].wqkv + (size_t)j * D * D * esize(T), D, D, D, T, false};
+        }
+        ab.cur = align256(ab.cur + (size_t)3 * D * D * esize(T));
+        lo[l].bqkv = ab.cur;
+        for (int j = 0; j < 3; ++j)
+            if (has_qkv_bias)
+                (*ab.slots)[pre + names[j] + ".bias"] = Slot{lo[l].bqkv + (size_t)j * D * 4, 1, D, D, VIT_F32, false};
+        ab.cur = align256(ab.cur + (size_t)3 * D * 4);
+        lo[l].wo = ab.add(pre + o + ".weight", D, D, D, T);
+        lo[l].bo = ab.add(pre + o + ".bias", 1, D, D, VIT_F32);
+        lo[l].w1 = ab.add(pre + "mlp.fc1.weight", F, D, D, T);
+        lo[l].b1 = ab.add(pre + "mlp.fc1.bias", 1, F, F, VIT_F32);
+        lo[l].w2 = ab.add(pre + "mlp.fc2.weight", D, F, F, T);
+        lo[l].b2 = ab.add(pre + "mlp.fc2.bias", 1, D, D, VIT_F32);
+    }
+    if (!clip) {
+        o_fin_g = ab.add("layernorm.weight", 1, D, D, VIT_F32);
+        o_fin_b = ab.add("layernorm.bias", 1, D, D, VIT_F32);
+    } else {
+        o_fin_g = ab.add("post_layernorm.weight", 1, D, D, VIT_F32);
+        o_fin_b = ab.add("post_layernorm.bias", 1, D, D, VIT_F32);
+    }
+    ctx->arena_bytes = ab.cur;
+    hipError_t e = hipMalloc((void**)&ctx->arena, ctx->arena_bytes);
+    if (e != hipSuccess) {
+        delete ctx;
+        return vit_set_error(VIT_E_NOMEM, "vit_create: hipMalloc(%zu) failed: %s", ab.cur, hipGetErrorString(e));
+    }
+    e = hipMemset(ctx->arena, 0, ctx->arena_bytes);  // K padding and absent biases read as zero
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // loads may come on any stream
+    if (e != hipSuccess) {
+        (void)hipFree(ctx->arena);
+        delete ctx;
+        return vit_set_error(VIT_E_HIP, "vit_create: hipMemset failed: %s", hipGetErrorString(e));
+    }
+    unsigned char* A = ctx->arena;
+    ctx->patch_w = A + o_patch_w;
+    ctx->patch_b = (float*)(A + o_patch_b);
+    ctx->cls = (float*)(A + o_cls);
+    ctx->pos = (float*)(A + o_pos);
+    ctx->pre_g = (float*)(A + o_pre_g);
+    ctx->pre_b = (float*)(A + o_pre_b);
+    ctx->fin_g = (float*)(A + o_fin_g);
+    ctx->fin_b = (float*)(A + o_fin_b);
+    ctx->layers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        LayerW& w = ctx->layers[l];
+        w.ln1_g = (float*)(A + lo[l].ln1g); w.ln1_b = (float*)(A + lo[l].ln1b);
+        w.ln2_g = (float*)(A + lo[l].ln2g); w.ln2_b = (float*)(A + lo[l].ln2b);
+        w.bqkv = (float*)(A + lo[l].bqkv); w.bo = (float*)(A + lo[l].bo);
+        w.b1 = (float*)(A + lo[l].b1); w.b2 = (float*)(A + lo[l].b2);
+        w.wqkv = A + lo[l].wqkv; w.wo = A + lo[l].wo; w.w1 = A + lo[l].w1; w.w2 = A + lo[l].w2;
+    }
+    ctx->n_missing = (int)ctx->slots.size();
+    *out = ctx;
+    return VIT_OK;
+}
+
+extern "C" int vit_destroy(vit_ctx* ctx) {
+    if (!ctx) return VIT_OK;
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    delete ctx;
+    return VIT_OK;
+}
+
+extern "C" int vit_load_weight(vit_ctx* ctx, const char* name, const void* src_dev, int src_dtype, int64_t numel,
+                               void* stream) {
+    VIT_REQUIRE(ctx && name && src_dev, "vit_load_weight: null argument");
+    VIT_REQUIRE(src_dtype == VIT_F32 || src_dtype == VIT_BF16, "vit_load_weight: bad source dtype %d", src_dtype);
+    auto it = ctx->slots.find(name);
+    if (it == ctx->slots.end()) return vit_set_error(VIT_E_INVALID, "vit_load_weight: unexpected key '%s'", name);
+    Slot& s = it->second;
+    if (numel != s.rows * s.cols)
+        return vit_set_error(VIT_E_INVALID, "vit_load_weight: '%s' has %lld elements, expected %lld", name,
+                             (long long)numel, (long long)(s.rows * s.cols));
+    int rc = launch_convert_2d(src_dev, src_dtype, ctx->arena + s.offset, s.dtype, s.rows, s.cols, s.pitch,
+                               (hipStream_t)stream);
+    if (rc == VIT_OK && !s.loaded) {
+        s.loaded = true;
+        --ctx->n_missing;
+    }
+    return rc;
+}
+
+extern "C" int vit_missing_weights(vit_ctx* ctx, const char** first_missing) {
+    if (!ctx) return vit_set_error(VIT_E_INVALID, "vit_missing_weights: null context");
+    int n = 0;
+    for (auto& kv : ctx->slots)
+        if (!kv.second.loaded) {
+            if (n == 0) ctx->missing_name = kv.first;
+            ++n;
+        }
+    if (first_missing) *first_missing = n ? ctx->missing_name.c_str() : nullptr;
+    return n;
+}
+
+// ---------------------------------------------------------------- forward
+namespace {
+struct Workspace {
+    size_t x, ln, qkv, ctxv, h, pix, total;
+};
+Workspace plan_workspace(const vit_ctx* ctx, int batch) {
+    const vit_config& c = ctx->cfg;
+    const size_t M = (size_t)batch * ctx->N, es = esize(c.dtype);
+    Workspace w{};
+    size_t cur = 0;
+    auto take = [&](size_t bytes) { size_t o = cur; cur = align256(cur + bytes); return o; };
+    w.x = take(M * c.hidden_size * es);
+    w.ln = take(M * c.hidden_size * es);
+    w.qkv = take(M * 3 * c.hidden_size * es);
+    w.ctxv = take(M * c.hidden_size * es);
+    w.h = take(M * c.intermediate_size * es);
+    w.pix = take((size_t)batch * c.num_channels * c.image_size * c.image_size * es);
+    w.total = cur;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t vit_workspace_bytes(const vit_ctx* ctx, int batch) {
+    if (!ctx || batch <= 0) return 0;
+    return plan_workspace(ctx, batch).total;
+}
+
+#define VIT_TRY(expr)                 \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != VIT_OK) return _rc; \
+    } while (0)
+
+extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
+                           void* pooled_out, void* workspace, size_t workspace_bytes, void* stream_) {
+    VIT_REQUIRE(ctx && pixels_dev && hidden_out && workspace, "vit_forward: null argument");
+    VIT_REQUIRE(batch > 0, "vit_forward: batch must be positive (got %d)", batch);
+    VIT_REQUIRE(pixel_dtype == VIT_F32 || pixel_dtype == VIT_BF16, "vit_forward: bad pixel dtype %d", pixel_dtype);
+    VIT_REQUIRE(((uintptr_t)workspace & 255) == 0, "vit_forward: workspace must be 256-byte aligned");
+    const char* missing = nullptr;
+    const int nmiss = ctx->n_missing ? vit_missing_weights(ctx, &missing) : 0;
+    if (nmiss) return vit_set_error(VIT_E_STATE, "vit_forward: %d weights not loaded (e.g. '%s')", nmiss, missing);
+    int dev;
+    VIT_CHECK_HIP(hipGetDevice(&dev));
+    if (dev != ctx->device)
+        return vit_set_error(VIT_E_STATE, "vit_forward: context lives on device %d, current device is %d", ctx->device, dev);
+    const Workspace w = plan_workspace(ctx, batch);
+    if (workspace_bytes < w.total)
+        return vit_set_error(VIT_E_NOMEM, "vit_forward: workspace %zu < required %zu bytes", workspace_bytes, w.total);
+
+    hipStream_t stream = (hipStream_t)stream_;
+    const vit_config& c = ctx->cfg;
+    const int T = c.dtype, D = c.hidden_size, F = c.intermediate_size, N = ctx->N, H = c.num_attention_heads;
+    const int M = batch * N;
+    const size_t es = esize(T);
+    unsigned char* ws = (unsigned char*)workspace;
+    void* x = ws + w.x;
+    void* ln = ws + w.ln;
+    void* qkv = ws + w.qkv;
+    void* cx = ws + w.ctxv;
+    void* h = ws + w.h;
+    const bool clip = c.variant == VIT_VARIANT_CLIP;
+    const int act_epi = c.hidden_act == VIT_ACT_GELU ? VIT_EPI_GELU : VIT_EPI_QUICK_GELU;
+
+    // embeddings (modeling_vit.py:129-161 / modeling_clip.py:202-218)
+    const void* pix = pixels_dev;
+    if (pixel_dtype != T) {
+        const int64_t n = (int64_t)batch * c.num_channels * c.image_size * c.image_size;
+        VIT_TRY(launch_convert(pixels_dev, pixel_dtype, ws + w.pix, T, n, stream));
+        pix = ws + w.pix;
+    }
+    VIT_TRY(launch_cls_rows(ctx->cls, ctx->pos, x, batch, N, D, T, stream));
+    PatchGeom pg{c.num_channels, c.image_size, c.patch_size, c.image_size / c.patch_size, ctx->kreal};
+    VIT_TRY(launch_gemm(pix, ctx->patch_w, ctx->patch_b, nullptr, x, batch * (N - 1), D, ctx->kpad, VIT_EPI_BIAS, T, &pg,
+                        ctx->pos, stream));
+    if (clip) VIT_TRY(launch_layernorm(x, ctx->pre_g, ctx->pre_b, x, M, D, D, D, c.layer_norm_eps, T, stream));
+
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        const LayerW& lw = ctx->layers[l];
+        const bool last = (l == c.num_hidden_layers - 1);
+        // x + Attn(LN1(x))   (modeling_vit.py:273-277)
+        VIT_TRY(launch_layernorm(x, lw.ln1_g, lw.ln1_b, ln, M, D, D, D, c.layer_norm_eps, T, stream));
+        VIT_TRY(launch_gemm(ln, lw.wqkv, lw.bqkv, nullptr, qkv, M, 3 * D, D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
+        VIT_TRY(launch_attention(qkv, cx, batch, N, H, ctx->dh, T, stream));
+        VIT_TRY(launch_gemm(cx, lw.wo, lw.bo, x, x, M, D, D, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream));
+        // x + MLP(LN2(x))    (modeling_vit.py:280-284)
+        VIT_TRY(launch_layernorm(x, lw.ln2_g, lw.ln2_b, ln, M, D, D, D, c.layer_norm_eps, T, stream));
+        VIT_TRY(launch_gemm(ln, lw.w1, lw.b1, nullptr, h, M, F, D, act_epi, T, nullptr, nullptr, stream));
+        // CLIP returns the un-normed stream: let the last fc2 write it straight to hidden_out
+        void* dst = (clip && last) ? hidden_out : x;
+        VIT_TRY(launch_gemm(h, lw.w2, lw.b2, x, dst, M, D, F, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream));
+    }
+    if (!clip) {
+        // final LayerNorm over all tokens; pooled = its CLS row (modeling_vit.py:385-388, no pooler)
+        VIT_TRY(launch_layernorm(x, ctx->fin_g, ctx->fin_b, hidden_out, M, D, D, D, c.layer_norm_eps, T, stream));
+        if (pooled_out)
+            VIT_TRY(launch_layernorm(x, ctx->fin_g, ctx->fin_b, pooled_out, batch, D, (int64_t)N * D, D,
+                                     c.layer_norm_eps, T, stream));
+    } else if (pooled_out) {
+        // post_layernorm on the CLS row only (modeling_clip.py:649-651)
+        VIT_TRY(launch_layernorm(hidden_out, ctx->fin_g, ctx->fin_b, pooled_out, batch, D, (int64_t)N * D, D,
+                                 c.layer_norm_eps, T, stream));
+    }
+    (void)es;
+    return VIT_OK;
+}
+
+// ---------------------------------------------------------------- per-kernel entry points
+extern "C" int vit_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int rows, int dim,
+                                 int64_t x_row_stride, int64_t y_row_stride, float eps, int dtype, void* stream) {
+    VIT_REQUIRE(x && gamma && beta && y, "vit_layernorm_fwd: null argument");
+    return launch_layernorm(x, gamma, beta, y, rows, dim, x_row_stride, y_row_stride, eps, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vit_gemm_bias_act(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,
+                                 int N, int K, int epilogue, int dtype, void* stream) {
+    VIT_REQUIRE(A && W && C, "vit_gemm_bias_act: null argument");
+    VIT_REQUIRE(epilogue >= VIT_EPI_BIAS && epilogue <= VIT_EPI_RESIDUAL, "vit_gemm_bias_act: bad epilogue %d", epilogue);
+    return launch_gemm(A, W, bias, residual, C, M, N, K, epilogue, dtype, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int vit_attention_fwd(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, int dtype,
+                                 void* stream) {
+    VIT_REQUIRE(qkv && out, "vit_attention_fwd: null argument");
+    return launch_attention(qkv, out, batch, seq, heads, head_dim, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vit_patch_embed_fwd(const void* pixels, const void* weight, const float* bias, const float* cls,
+                                   const float* pos, void* x_out, int batch, int channels, int image, int patch, int dim,
+                                   int dtype, void* stream) {
+    VIT_REQUIRE(pixels && weight && cls && pos && x_out, "vit_patch_embed_fwd: null argument");
+    VIT_REQUIRE(batch > 0 && channels > 0 && patch > 0 && image > 0 && image % patch == 0 && dim > 0,
+                "vit_patch_embed_fwd: bad geometry");
+    const int g = image / patch, N = g * g + 1;
+    PatchGeom pg{channels, image, patch, g, channels * patch * patch};
+    VIT_TRY(launch_cls_rows(cls, pos, x_out, batch, N, dim, dtype, (hipStream_t)stream));
+    return launch_gemm(pixels, weight, bias, nullptr, x_out, batch * (N - 1), dim, vit_patch_kpad(channels, patch, dtype),
+                       VIT_EPI_BIAS, dtype, &pg, pos, (hipStream_t)stream);
+}
+
+extern "C" int vit_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, void* stream) {
+    VIT_REQUIRE(src && dst, "vit_convert: null argument");
+    return launch_convert(src, src_dtype, dst, dst_dtype, numel, (hipStream_t)stream);
+}

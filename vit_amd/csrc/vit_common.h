@@ -1,0 +1,73 @@
+// Shared device/host helpers for the gfx950 ViT kernels. CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vit_amd.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// error plumbing (vit_capi.hip)
+int vit_set_error(int code, const char* fmt, ...);
+#define VIT_CHECK_HIP(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) return vit_set_error(VIT_E_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define VIT_REQUIRE(cond, ...)                                      \
+    do {                                                            \
+        if (!(cond)) return vit_set_error(VIT_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- activations (fp32 math) ----
+__device__ __forceinline__ float act_gelu_erf(float x) {
+    // exact GELU: 0.5 x (1 + erf(x / sqrt 2))   (configuration_vit.py:54, ACT2FN["gelu"])
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_quick_gelu(float x) {
+    // x * sigmoid(1.702 x)   (configuration_clip.py:105, ACT2FN["quick_gelu"])
+    return x / (1.0f + __expf(-1.702f * x));
+}
+
+template <int EPI>
+__device__ __forceinline__ float apply_act(float v) {
+    if constexpr (EPI == VIT_EPI_GELU) return act_gelu_erf(v);
+    if constexpr (EPI == VIT_EPI_QUICK_GELU) return act_quick_gelu(v);
+    return v;
+}
+
+// wave-wide sum over 64 lanes
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// internal launchers (one per .hip file), all async on `stream`
+int launch_layernorm(const void* x, const float* g, const float* b, void* y, int rows, int dim, int64_t xs,
+                     int64_t ys, float eps, int dtype, hipStream_t stream);
+
+struct PatchGeom {  // im2col-free A operand of the patch-embedding GEMM
+    int channels, image, patch, grid;  // grid = image / patch
+    int kreal;                         // C*P*P (k >= kreal reads as zero)
+};
+
+// C = epi(A W^T + bias (+res)); `patch` non-null => A is the pixel tensor, rows are patches,
+// output rows are remapped past the CLS slot and `pos` (fp32 [N,D]) is added.
+int launch_gemm(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
+                int epi, int dtype, const PatchGeom* patch, const float* pos, hipStream_t stream);
+int launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, int dtype,
+                     hipStream_t stream);
+int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t stream);
+int launch_cls_rows(const float* cls, const float* pos, void* x, int batch, int seq, int dim, int dtype,
+                    hipStream_t stream);

@@ -1,0 +1,144 @@
+"""Host-side mirror of the encoder interface (``ViTModel`` / ``CLIPVisionModel`` call
+surface: ``pixel_values`` in, ``last_hidden_state`` / ``pooler_output`` out) over the C ABI.
+
+The reference repository's scripts hand an encoded image to a remote VLM
+(Vlm_coder.py:205,381; vlm_cad.py:171) -- a local encoder slots in right before those
+calls; see INTEGRATION.md. The whole forward runs inside ``vit_forward`` (libvit_amd.so);
+torch only owns the tensors, the workspace and the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Mapping, Optional
+
+import torch
+
+from . import _lib
+from .config import ViTConfig
+from .ops import dtype_code
+
+
+@dataclass
+class EncoderOutput:
+    """Same field names as transformers' BaseModelOutputWithPooling."""
+    last_hidden_state: torch.Tensor
+    pooler_output: torch.Tensor
+
+    def __iter__(self):
+        yield self.last_hidden_state
+        yield self.pooler_output
+
+
+class ViTEncoder:
+    """MI355X ViT / CLIP-vision encoder.
+
+    >>> enc = ViTEncoder(ViTConfig(), dtype=torch.bfloat16, device="cuda:0")
+    >>> enc.load_state_dict(hf_state_dict)      # HF key names
+    >>> out = enc(pixel_values)                 # out.last_hidden_state [B,N,D], out.pooler_output [B,D]
+    """
+
+    def __init__(self, config: ViTConfig, dtype: torch.dtype = torch.bfloat16, device="cuda"):
+        self.config = config
+        self.dtype = dtype
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("ViTEncoder runs on the GPU only (no CPU fallback); pass device='cuda[:i]'")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        lib = _lib.load()
+        cfg = _lib.vit_config(
+            hidden_size=config.hidden_size, num_hidden_layers=config.num_hidden_layers,
+            num_attention_heads=config.num_attention_heads, intermediate_size=config.intermediate_size,
+            image_size=config.image_size, patch_size=config.patch_size, num_channels=config.num_channels,
+            hidden_act=config.act_id, variant=config.variant_id, qkv_bias=int(config.qkv_bias),
+            dtype=dtype_code(dtype), layer_norm_eps=config.layer_norm_eps)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.vit_create(ctypes.byref(cfg), ctypes.byref(handle)))
+        self._ctx = handle
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- weights ----
+    def load_state_dict(self, state_dict: Mapping[str, torch.Tensor], strict: bool = True) -> None:
+        """Feed an HF-style state dict (``ViTModel`` or ``CLIPVisionModel`` key names; an
+        optional ``vit.`` / ``vision_model.`` prefix is stripped). q/k/v are packed inside the
+        library. With strict=True unknown keys and missing tensors raise."""
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            for key, t in state_dict.items():
+                name = key
+                for prefix in ("vit.", "vision_model."):
+                    if name.startswith(prefix):
+                        name = name[len(prefix):]
+                if not torch.is_tensor(t) or not t.is_floating_point():
+                    continue
+                if t.dtype not in (torch.float32, torch.bfloat16):
+                    t = t.float()
+                src = t.to(self.device).contiguous()
+                rc = lib.vit_load_weight(self._ctx, name.encode(), src.data_ptr(), dtype_code(src.dtype), src.numel(),
+                                         stream)
+                if rc != 0:
+                    msg = lib.vit_last_error().decode()
+                    if not strict and "unexpected key" in msg:
+                        continue
+                    raise _lib.VitError(rc, msg)
+            torch.cuda.current_stream().synchronize()  # sources may be temporaries
+        if strict:
+            first = ctypes.c_char_p()
+            n = lib.vit_missing_weights(self._ctx, ctypes.byref(first))
+            if n:
+                raise KeyError(f"{n} tensors missing from state_dict, e.g. {first.value.decode()!r}")
+
+    # ---- forward ----
+    def workspace_bytes(self, batch: int) -> int:
+        return int(_lib.load().vit_workspace_bytes(self._ctx, batch))
+
+    def _workspace(self, batch: int) -> torch.Tensor:
+        need = self.workspace_bytes(batch)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, pixel_values: torch.Tensor) -> EncoderOutput:
+        cfg = self.config
+        if pixel_values.dim() != 4:
+            raise ValueError("pixel_values must be [batch, channels, height, width]")
+        b, c, h, w = pixel_values.shape
+        if c != cfg.num_channels:
+            # same check as ViTPatchEmbeddings.forward (modeling_vit.py:63-68)
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
+                             f"configuration. Expected {cfg.num_channels} but got {c}.")
+        if h != cfg.image_size or w != cfg.image_size:
+            # same check as ViTEmbeddings.forward (modeling_vit.py:151-155)
+            raise ValueError(f"Input image size ({h}*{w}) doesn't match model ({cfg.image_size}*{cfg.image_size}).")
+        if b == 0:
+            return EncoderOutput(torch.empty(0, cfg.seq_len, cfg.hidden_size, dtype=self.dtype, device=self.device),
+                                 torch.empty(0, cfg.hidden_size, dtype=self.dtype, device=self.device))
+        if pixel_values.dtype not in (torch.float32, torch.bfloat16):
+            pixel_values = pixel_values.float()
+        px = pixel_values.to(self.device).contiguous()
+        hidden = torch.empty(b, cfg.seq_len, cfg.hidden_size, dtype=self.dtype, device=self.device)
+        pooled = torch.empty(b, cfg.hidden_size, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._workspace(b)
+            _lib.check(_lib.load().vit_forward(self._ctx, px.data_ptr(), dtype_code(px.dtype), b, hidden.data_ptr(),
+                                               pooled.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               torch.cuda.current_stream().cuda_stream))
+        return EncoderOutput(hidden, pooled)
+
+    __call__ = forward
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            torch.cuda.synchronize(self.device)
+            _lib.load().vit_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
