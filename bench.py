@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, ViT-B/16 224^2 bf16 forward (BASELINE.json configs[1]).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one forward of the hot path (vit_forward through the C ABI) over one batch of 256
+synthetic images per GPU, already resident in HBM; for N > 1 the batch is sharded (weak
+scaling, 256 images per rank) and the step ends with the RCCL all-gather of the CLS
+embeddings. W untimed steps, then exactly K timed steps bracketed by barrier +
+torch.cuda.synchronize(); the time is the MAX over ranks; rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      dominant kernel (the bf16 MFMA GEMM instance that takes the most time per
+                forward): algorithmic FLOPs per launch / average launch duration measured live
+                with events on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  kernels       the same measurement for every kernel of the path (GEMMs/attention vs MFMA
+                peak, LayerNorm vs 8 TB/s HBM).
+  cpu_baseline  the CPU oracle (oracle/vit_oracle.py, fp32, batch 8) timed on this box's host
+                cores (rank 0, N = 1 only) -- a reported baseline, not a target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vit_amd import ops, synth  # noqa: E402
+from vit_amd.config import ViTConfig  # noqa: E402
+from vit_amd.encoder import ViTEncoder  # noqa: E402
+
+MFMA_BF16_PEAK = 2.5e15  # dense bf16 FLOP/s, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+HBM_PEAK = 8.0e12        # bytes/s spec, same guide
+LOCAL_BATCH = 256
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def time_kernel(fn, iters=20, warm=3):
+    """Average launch duration in seconds, events recorded on the launch (current) stream."""
+    for _ in range(warm):
+        fn()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / iters
+
+
+def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
+    """Per-kernel live measurement at the bench shapes (synthetic N(0,1)-scale operands)."""
+    m, d, f, n, h = batch * cfg.seq_len, cfg.hidden_size, cfg.intermediate_size, cfg.seq_len, cfg.num_attention_heads
+    bf = torch.bfloat16
+
+    def t(shape, name, std=1.0):
+        return synth.normal(shape, 11, name, std=std, device=dev).to(bf)
+
+    x, hid = t((m, d), "x"), t((m, f), "h")
+    wqkv, wo, w1, w2 = t((3 * d, d), "wqkv", 0.02), t((d, d), "wo", 0.02), t((f, d), "w1", 0.02), t((d, f), "w2", 0.02)
+    bqkv, bo, b1 = [synth.normal((k,), 11, nm, 0.05, device=dev) for k, nm in ((3 * d, "bq"), (d, "bo"), (f, "b1"))]
+    qkv = t((batch, n, 3 * d), "qkv")
+    g, b = synth.normal((d,), 11, "g", 0.1, 1.0, device=dev), synth.normal((d,), 11, "b", 0.05, device=dev)
+    px = synth.synthetic_images(cfg, batch, seed=3, device=dev).to(bf)
+    pw = t((d, cfg.num_channels, cfg.patch_size, cfg.patch_size), "pw", 0.02)
+    cls, pos = synth.normal((d,), 11, "cls", device=dev), synth.normal((n, d), 11, "pos", device=dev)
+    L = cfg.num_hidden_layers
+    specs = [  # name, launches per forward, callable, flops per launch, bytes per launch (HBM-bound kernels)
+        ("gemm_qkv", L, lambda: ops.linear(x, wqkv, bqkv), 2 * m * 3 * d * d, None),
+        ("gemm_o_proj_res", L, lambda: ops.linear(x, wo, bo, residual=x), 2 * m * d * d, None),
+        ("gemm_fc1_gelu", L, lambda: ops.linear(x, w1, b1, activation=cfg.hidden_act), 2 * m * f * d, None),
+        ("gemm_fc2_res", L, lambda: ops.linear(hid, w2, bo, residual=x), 2 * m * d * f, None),
+        ("attention", L, lambda: ops.attention(qkv, h), 4 * batch * h * n * n * cfg.head_dim, None),
+        ("layernorm", 2 * L + 1, lambda: ops.layer_norm(x, g, b, cfg.layer_norm_eps), None, 2 * m * d * 2),
+        ("patch_embed", 1, lambda: ops.patch_embed(px, pw, bo, cls, pos, cfg.patch_size),
+         2 * batch * cfg.num_patches * cfg.patch_dim * d, None),
+    ]
+    out = {}
+    for name, per_fwd, fn, flops, nbytes in specs:
+        dt = time_kernel(fn)
+        if flops is not None:
+            ach = flops / dt
+            out[name] = {"bound": "mfma", "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_BF16_PEAK, "us_per_launch": dt * 1e6, "launches_per_forward": per_fwd}
+        else:
+            ach = nbytes / dt
+            out[name] = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK, "us_per_launch": dt * 1e6, "launches_per_forward": per_fwd}
+    return out
+
+
+def cpu_baseline(cfg: ViTConfig, budget_s: float = 12.0):
+    """The CPU oracle on this host: fp32, batch 8 (BASELINE.json configs[0])."""
+    from oracle import vit_oracle
+    sd = synth.synthetic_state_dict(cfg, seed=0)
+    px = synth.synthetic_images(cfg, 8, seed=1)
+    vit_oracle.forward(px, sd, cfg)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        vit_oracle.forward(px, sd, cfg)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 50:
+            break
+    return {"value": 8 * n / el, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} forwards of batch 8, ViT-B/16 224^2 fp32, oracle/vit_oracle.py (plain torch CPU)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    cfg = ViTConfig.vit_b16_224()
+    enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=dev)
+    enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0, device=dev))
+    px = synth.synthetic_images(cfg, LOCAL_BATCH, seed=1 + rank, device=dev).to(torch.bfloat16)
+    gathered = torch.empty(world * LOCAL_BATCH, cfg.hidden_size, dtype=torch.bfloat16, device=dev) if world > 1 else None
+
+    def step():
+        out = enc(px)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out.pooler_output)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(out.pooler_output).all(), "non-finite embeddings"
+
+    if rank == 0:
+        images = world * LOCAL_BATCH * args.steps
+        value = images / elapsed
+        flops = value * cfg.flops_per_image()
+        line = {
+            "metric": "images/sec ViT-B/16 224^2 bf16 forward", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ViT-B/16 224^2 bf16 forward, batch 256 per MI355X (BASELINE.json configs[1])",
+                       "global_batch": world * LOCAL_BATCH, "seq_len": cfg.seq_len,
+                       "parallelism": f"dp{world}" + (" + RCCL all-gather of CLS embeddings" if world > 1 else "")},
+            "end_to_end": {"achieved": flops / 1e12, "peak": world * MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                           "frac": flops / (world * MFMA_BF16_PEAK)},
+        }
+        if not args.no_kernels:
+            ks = kernel_rooflines(cfg, LOCAL_BATCH, dev)
+            dom = max((k for k in ks if k.startswith("gemm")),
+                      key=lambda k: ks[k]["us_per_launch"] * ks[k]["launches_per_forward"])
+            r = ks[dom]
+            line["roofline"] = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                                "frac": r["frac"], "traffic": None, "kernel": "gemm_bf16_kernel (" + dom + ")",
+                                "us_per_launch": r["us_per_launch"]}
+            line["kernels"] = ks
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,8 +111,9 @@ def patch_embed(pixel_values: torch.Tensor, weight: torch.Tensor, bias: torch.Te
     d = weight.shape[0]
     kreal = c * patch_size * patch_size
     kpad = _lib.load().vit_patch_kpad(c, patch_size, dt)
-    wmat = torch.zeros(d, kpad, dtype=px.dtype, device=px.device)
-    wmat[:, :kreal] = _dev(weight, "weight").reshape(d, kreal).to(px.dtype)
+    wmat = _dev(weight, "weight").reshape(d, kreal).to(px.dtype)
+    if kpad != kreal:  # zero-pad K to the kernel's 16-byte chunk granularity
+        wmat = torch.nn.functional.pad(wmat, (0, kpad - kreal))
     n = (h // patch_size) ** 2 + 1
     cls = _f32(cls_token, "cls_token").reshape(d)
     pos = _f32(position_embeddings, "position_embeddings").reshape(n, d)
