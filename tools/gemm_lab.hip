@@ -2,7 +2,10 @@
 // against the shipped kernel on the ViT-B/16 batch-256 shapes, random bf16 operands,
 // interleaved rounds in one process (cdna_hip_programming.md rule 24).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/gemm_lab.hip -o tools/gemm_lab
+#define G8_LAB 1
+#include <type_traits>
 #include "../vit_amd/csrc/gemm_bf16.hip"
+#include "../vit_amd/csrc/gemm_bf16_8p.hip"
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -163,30 +166,39 @@ static void fill(std::vector<uint16_t>& v, float scale, unsigned seed) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const char* shape_f = argc > 1 ? argv[1] : "";
+    const char* var_f = argc > 2 ? argv[2] : "";
+    const int rounds = argc > 3 ? atoi(argv[3]) : 5;
     struct Shape { const char* name; int M, N, K; int epi; };
     Shape shapes[] = {{"qkv", 50432, 2304, 768, VIT_EPI_BIAS}, {"oproj", 50432, 768, 768, VIT_EPI_BIAS},
                       {"fc1", 50432, 3072, 768, VIT_EPI_BIAS}, {"fc1_gelu", 50432, 3072, 768, VIT_EPI_GELU},
-                      {"fc2", 50432, 768, 3072, VIT_EPI_BIAS}};
+                      {"fc2", 50432, 768, 3072, VIT_EPI_BIAS}, {"oproj_res", 50432, 768, 768, VIT_EPI_RESIDUAL},
+                      {"fc2_res", 50432, 768, 3072, VIT_EPI_RESIDUAL}, {"ragged", 1000, 1000, 640, VIT_EPI_RESIDUAL}, {"ragged_g", 300, 520, 256, VIT_EPI_GELU}};
     hipStream_t st; hipStreamCreate(&st);
     for (auto& sh : shapes) {
+        if (*shape_f && strcmp(shape_f, "all") && strcmp(shape_f, sh.name)) continue;
         const size_t na = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, nc = (size_t)sh.M * sh.N;
         std::vector<uint16_t> ha(na), hw(nw);
         fill(ha, 1.0f, 1); fill(hw, 0.05f, 2);
         std::vector<float> hb(sh.N);
         for (int j = 0; j < sh.N; ++j) hb[j] = 0.01f * (j % 37 - 18);
-        bf16_t *A, *W, *C0, *C1; float* B;
-        hipMalloc(&A, na * 2); hipMalloc(&W, nw * 2); hipMalloc(&C0, nc * 2); hipMalloc(&C1, nc * 2); hipMalloc(&B, sh.N * 4);
+        bf16_t *A, *W, *C0, *C1, *R; float* B;
+        hipMalloc(&A, na * 2); hipMalloc(&W, nw * 2); hipMalloc(&C0, nc * 2); hipMalloc(&C1, nc * 2); hipMalloc(&B, sh.N * 4); hipMalloc(&R, nc * 2);
+        { std::vector<uint16_t> hr(nc); fill(hr, 1.0f, 3); hipMemcpy(R, hr.data(), nc * 2, hipMemcpyHostToDevice); }
         hipMemcpy(A, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(W, hw.data(), nw * 2, hipMemcpyHostToDevice);
         hipMemcpy(B, hb.data(), sh.N * 4, hipMemcpyHostToDevice);
         GemmParams P{}; P.A = A; P.W = W; P.bias = B; P.M = sh.M; P.N = sh.N; P.K = sh.K;
         struct Var { const char* name; std::function<void(bf16_t*)> run; };
         const bool gelu = sh.epi == VIT_EPI_GELU;
         std::vector<Var> vars;
-        vars.push_back({"shipped", [&](bf16_t* C) { launch_gemm_bf16(A, W, B, nullptr, C, sh.M, sh.N, sh.K, sh.epi, nullptr, nullptr, st); }});
+        vars.push_back({"shipped", [&](bf16_t* C) { launch_gemm_bf16_generic(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, nullptr, st); }});
         vars.push_back({"ring<2,4,4>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<2, 4, 4, VIT_EPI_GELU>(Q, st) : lab::launch_ring<2, 4, 4, VIT_EPI_BIAS>(Q, st); }});
+        vars.push_back({"g8p", [&](bf16_t* C) { launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, st); }});
+        vars.push_back({"ns8p", [&](bf16_t* C) { g8_dbg = 1; launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, st); g8_dbg = 0; }});
         vars.push_back({"ring<2,2,3>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<2, 2, 3, VIT_EPI_GELU>(Q, st) : lab::launch_ring<2, 2, 3, VIT_EPI_BIAS>(Q, st); }});
         vars.push_back({"ring<1,4,3>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<1, 4, 3, VIT_EPI_GELU>(Q, st) : lab::launch_ring<1, 4, 3, VIT_EPI_BIAS>(Q, st); }});
+        if (*var_f) { std::vector<Var> keep; for (auto& v : vars) if (!strcmp(v.name, "shipped") || strstr(var_f, v.name)) keep.push_back(v); vars = keep; }
         // correctness vs shipped
         vars[0].run(C0); hipStreamSynchronize(st);
         std::vector<uint16_t> h0(nc), h1(nc);
@@ -201,7 +213,7 @@ int main() {
             printf("%-9s %-12s mismatches vs shipped: %zu / %zu (%s)\n", sh.name, vars[v].name, bad, nc, hipGetErrorString(e));
         }
         // timing: interleaved rounds
-        const int rounds = 5, iters = 10;
+        const int iters = 10;
         std::vector<std::vector<float>> ms(vars.size());
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int r = 0; r < rounds; ++r)
@@ -218,7 +230,7 @@ int main() {
             printf("%-9s %-12s median %8.1f us  %7.1f TF   (min %8.1f us)\n", sh.name, vars[v].name, ms[v][rounds / 2] * 1e3,
                    flop / (ms[v][rounds / 2] * 1e-3) / 1e12, ms[v][0] * 1e3);
         }
-        hipFree(A); hipFree(W); hipFree(C0); hipFree(C1); hipFree(B);
+        hipFree(A); hipFree(W); hipFree(C0); hipFree(C1); hipFree(B); hipFree(R);
         fflush(stdout);
     }
     return 0;

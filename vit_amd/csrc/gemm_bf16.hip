@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const GemmParams
 #pragma unroll
         for (int b = 0; b < G::NI; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[b * 4 + j] = apply_act<EPI>(acc[a][b][j] + bias[b * 4 + j]);
+            for (int j = 0; j < 4; ++j) v[b * 4 + j] = apply_act_bf16<EPI>(acc[a][b][j] + bias[b * 4 + j]);
         size_t orow = (size_t)m;
         if constexpr (EPI == EPI_PATCH) {
             const int bimg = m / np, pr = m - bimg * np + 1;  // token index inside the image (CLS = 0)
@@ -296,11 +296,28 @@ int pick_bn(int M, int N) {
 
 }  // namespace
 
+bool gemm_bf16_8p_eligible(int M, int N, int K);
+int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
+                        int epi, hipStream_t stream);
+
+// generic tile kernel of this file (any K % 8 == 0, patch loaders); also the lab's baseline
+int launch_gemm_bf16_generic(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N,
+                             int K, int epi, const PatchGeom* patch, const float* pos, hipStream_t stream);
+
 int launch_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
                      int epi, const PatchGeom* patch, const float* pos, hipStream_t stream) {
     VIT_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     VIT_REQUIRE(K % 8 == 0 && N % 8 == 0, "gemm(bf16): K and N must be multiples of 8 (K=%d N=%d)", K, N);
     VIT_REQUIRE(epi != VIT_EPI_RESIDUAL || res != nullptr, "gemm: residual epilogue without residual");
+    // big Linear layers go to the persistent deep-pipelined kernel (gemm_bf16_8p.hip); tiny
+    // problems (less than one 256x256 tile of work per 4 CUs) and K tails stay here
+    if (patch == nullptr && gemm_bf16_8p_eligible(M, N, K) && (long)M * N >= 64L * 256 * 256)
+        return launch_gemm_bf16_8p(A, W, bias, res, C, M, N, K, epi, stream);
+    return launch_gemm_bf16_generic(A, W, bias, res, C, M, N, K, epi, patch, pos, stream);
+}
+
+int launch_gemm_bf16_generic(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N,
+                             int K, int epi, const PatchGeom* patch, const float* pos, hipStream_t stream) {
     GemmParams P{};
     P.A = (const bf16_t*)A; P.W = (const bf16_t*)W; P.bias = bias; P.res = (const bf16_t*)res; P.C = (bf16_t*)C;
     P.pos = pos; P.M = M; P.N = N; P.K = K;

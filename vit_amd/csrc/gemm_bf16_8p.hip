@@ -1,0 +1,370 @@
+// bf16 MFMA GEMM, persistent deep-pipelined kernel for the encoder's big Linear layers:
+//     C[M,N] = epi(A[M,K] * W[N,K]^T + bias (+ residual)),   K % 128 == 0, K >= 256
+// (q/k/v packed projection modeling_vit.py:216-218, o_proj + residual :236,:277, fc1 + GELU
+// :250-251, fc2 + residual :252,:284). Shapes it does not take (K tails, the im2col-free
+// patch loader) stay on gemm_bf16.hip.
+//
+// gfx950 design (DESIGN.md "GEMM"):
+//  * Persistent: one 512-thread workgroup per CU walks a list of 256 x 256 output tiles. Blocks
+//    b and b+8 share an XCD; each XCD label owns one contiguous chunk of the (mt-major) tile
+//    space and its blocks walk it together, so neighbouring tiles (same A panel) meet in one L2.
+//  * 256 x 256 x 64 block tile, 8 waves = 2 teams (wr) x 4 (wc), 128 KiB LDS = 2 K-tile buffers
+//    x {A_h0, A_h1, B_h0, B_h1} half-tiles (128 rows x 64 bf16 each). Wave (wr, wc) owns output
+//    rows {h*128 + wr*64 + [0,64)}, h = 0,1, and the 64 columns wc*64 + [0,64) (32 staged in each
+//    B half): one 64x32 quadrant per (A half, B half) pair.
+//  * A K-tile is 4 phases of 16 v_mfma_f32_16x16x32_bf16 (one quadrant x K=64):
+//        ph1 (A0,B0)  ph2 (A0,B1)  ph3 (A1,B1)  ph4 (A1,B0)
+//    Each phase = {ds_read_b128 this phase's new fragments, issue ONE half-tile of LDS-DMA
+//    (2 x buffer_load_dwordx4 ... lds per thread), s_barrier, lgkmcnt(0), 16 MFMA, s_barrier}.
+//    The two teams run staggered by one barrier, so on every SIMD one wave's MFMA section
+//    overlaps its partner's LDS-read / DMA-issue section.
+//  * Half-tiles retire at different phases (A_h0, B_h0 after ph1; B_h1 after ph2; A_h1 after
+//    ph3), so the DMA stream runs 3-4 half-tiles ahead of its consumer:
+//        ph1: stage B_h1(t+1)   ph2: stage A_h1(t+1)   ph3: stage A_h0(t+2)   ph4: stage B_h0(t+2)
+//    with counted waits only -- vmcnt(6) at ph1 (retires B_h1/A_h1 of the current K-tile, read
+//    from ph2/ph3 on) and vmcnt(8) at ph4 (retires A_h0/B_h0 of the next K-tile). Every buffer
+//    is restaged >= 2 phases after its last ds_read and read >= 1 phase after the wait that
+//    retires it (the rule for staggered wave groups).
+//  * The K-tile stream is continuous across output tiles: the last two K-tiles of a tile
+//    already stage the first two of the next one, so the DMA pipeline never drains.
+//  * LDS rows are 128 B; 16-B chunk c of row r sits at chunk position c ^ ((r>>1)&7). The DMA
+//    destination is lane-linear, so the swizzle is on the per-lane SOURCE offset and on the
+//    ds_read_b128 address: conflict-free fragment reads. DMA addresses are buffer-resource
+//    base (SGPR) + 32-bit lane offset + SGPR k offset: no 64-bit per-lane arithmetic.
+//  * Epilogue: weight rows are staged interleaved (LDS row wc*32 + ni*16 + c of B half h holds
+//    column wc*64 + 4c + 2h + ni), so the four 16-column fragments of a wave give every lane 4
+//    CONSECUTIVE columns and 16 lanes cover one full 128-byte line of an output row. Stores and
+//    residual loads go through buffer resources (hardware range check masks the ragged M/N
+//    edges, no branches); the residual tile is fetched up front into the dead fragment
+//    registers. Measured on MI355X (tools/store_lab.hip): this store shape moves a 128 KiB tile
+//    in 2.3 us per CU, the natural 16-rows-x-64-B MFMA shape needs 4.5 us.
+#include "vit_common.h"
+#include <type_traits>
+
+namespace g8 {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
+constexpr int HALF_BYTES = 128 * BK * 2;        // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;       // 64 KiB: A_h0, A_h1, B_h0, B_h1
+constexpr int LDS_BYTES = 2 * BUF_BYTES;        // 128 KiB
+constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
+
+#define G8_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define G8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// LDS-DMA through a buffer resource: address = resource base + per-lane byte offset (VGPR) +
+// wave-uniform byte offset (SGPR). No 64-bit per-lane address arithmetic.
+__device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int uni_off,
+                                         unsigned char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, (int)lane_off, uni_off, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent form: one workgroup per CU walks a list of output tiles. The K-tile stream is
+// continuous across tile boundaries (the last two K-tiles of a tile already stage the first
+// two K-tiles of the next tile), so the DMA pipeline never drains; the epilogue of both
+// teams runs in the same barrier interval.
+struct PParams {
+    const bf16_t* A;
+    const bf16_t* W;
+    const float* bias;
+    const bf16_t* res;
+    bf16_t* C;
+    int M, N, K;
+    int NT;      // tiles along N
+    int T;       // total tiles
+    int dbg;     // lab only (G8_LAB): bit0 = timing-only run without output stores
+};
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // ---- tile list of this workgroup. Blocks b and b+8 share an XCD (label x = b % XL); label
+    // x owns one contiguous chunk of the (mt-major) tile space and its blocks walk the chunk
+    // together, so an XCD's L2 sees neighbouring tiles (shared A panels / W panels).
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int XL = G < 8 ? G : 8;
+    const int x = bid % XL, l = bid / XL;
+    const int gx = (G - x + XL - 1) / XL;          // blocks with this label
+    const int tq = P.T / XL, tr = P.T % XL;
+    const int cnt = tq + (x < tr ? 1 : 0);         // tiles in this label's chunk
+    const int start = x * tq + (x < tr ? x : tr);
+    if (l >= cnt) return;                          // uniform per block, before any barrier
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int i = lane & 15, q = lane >> 4;
+    const int p = tid & 7;
+
+    unsigned a_of[2][2], w_of[2][2];          // per-lane byte offsets from the tile's first A / W row
+    __amdgpu_buffer_rsrc_t Ar, Wr;            // wave-uniform buffer resources based at those rows
+    auto set_tile = [&](int tile_idx) {   // staging offsets / bases for a tile
+        const int mt = tile_idx / P.NT, nt = tile_idx - mt * P.NT;
+        const int m0 = mt * BM, n0 = nt * BN;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = j * 64 + (tid >> 3);
+                const int sw = (r >> 1) & 7;
+                int ar = h * 128 + r;
+                if (m0 + ar > P.M - 1) ar = P.M - 1 - m0;
+                a_of[h][j] = ((unsigned)ar * (unsigned)P.K + (unsigned)((p ^ sw) << 3)) * 2u;
+                const int rr = r & 31;
+                // B half h, LDS row (wc*32 + ni*16 + c) holds tile column wc*64 + 4c + (2h + ni): the four
+                // 16-column MFMA fragments of a wave interleave to 4 consecutive columns per lane
+                int wrow = (r >> 5) * 64 + (rr & 15) * 4 + h * 2 + (rr >> 4);
+                if (n0 + wrow > P.N - 1) wrow = P.N - 1 - n0;
+                w_of[h][j] = ((unsigned)wrow * (unsigned)P.K + (unsigned)((p ^ sw) << 3)) * 2u;
+            }
+        // num_records spans the (clamped) 256 rows of the tile; offsets never exceed it
+        const unsigned span = (unsigned)BM * (unsigned)P.K * 2u;
+        Ar = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * P.K), 0, span, 0x00020000);
+        Wr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * P.K), 0, span, 0x00020000);
+    };
+    unsigned char* const dma_base = smem + wave * 1024;
+    auto stage_a = [&](int h, int buf, int kt) {
+        unsigned char* d = dma_base + buf * BUF_BYTES + (h ? OFF_A1 : OFF_A0);
+        bufdma16(Ar, a_of[h][0], kt * (BK * 2), d);
+        bufdma16(Ar, a_of[h][1], kt * (BK * 2), d + 8192);
+    };
+    auto stage_b = [&](int h, int buf, int kt) {
+        unsigned char* d = dma_base + buf * BUF_BYTES + (h ? OFF_B1 : OFF_B0);
+        bufdma16(Wr, w_of[h][0], kt * (BK * 2), d);
+        bufdma16(Wr, w_of[h][1], kt * (BK * 2), d + 8192);
+    };
+
+    const int sw = i >> 1;
+    const unsigned rd_a = (unsigned)((wr * 64 + i) * 128);
+    const unsigned rd_b = (unsigned)((wc * 32 + i) * 128);
+    const unsigned ck0 = (unsigned)((q ^ sw) << 4), ck1 = (unsigned)(((4 + q) ^ sw) << 4);
+
+    bf16x8 af[4][2];
+    bf16x8 bfr[2][2][2];
+    f32x4 acc[2][4][2][2];
+
+    auto read_a = [&](int buf, int h) {
+        const unsigned char* b0 = smem + buf * BUF_BYTES + (h ? OFF_A1 : OFF_A0) + rd_a;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            af[mi][0] = *(const bf16x8*)(b0 + mi * 2048 + ck0);
+            af[mi][1] = *(const bf16x8*)(b0 + mi * 2048 + ck1);
+        }
+    };
+    auto read_b = [&](int buf, int h) {
+        const unsigned char* b0 = smem + buf * BUF_BYTES + (h ? OFF_B1 : OFF_B0) + rd_b;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            bfr[h][ni][0] = *(const bf16x8*)(b0 + ni * 2048 + ck0);
+            bfr[h][ni][1] = *(const bf16x8*)(b0 + ni * 2048 + ck1);
+        }
+    };
+    // ZERO: first K-tile of an output tile -- the ks = 0 MFMA starts from a zero accumulator
+    auto mma = [&](int ha, int hb, auto ZEROC) {
+        constexpr bool ZERO = decltype(ZEROC)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const f32x4 c = (ZERO && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[ha][mi][hb][ni];
+                    acc[ha][mi][hb][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][ks], bfr[hb][ni][ks], c, 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define G8P_SECTION(HA, HB, Z)             \
+    __builtin_amdgcn_s_barrier();          \
+    G8_WAIT_LGKM0();                       \
+    __builtin_amdgcn_sched_barrier(0);     \
+    mma(HA, HB, Z);                        \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier()
+
+    const int nk = P.K / BK;  // even, >= 4 (checked on the host)
+
+    // MODE 0: steady; 1: K-tile nk-2 (after ph2 the DMA stream switches to the next tile);
+    // 2: K-tile nk-1 (all stages belong to the next tile). FIRST: K-tile 0 of a tile (its
+    // B_h1/A_h1 were retired before the loop / at the start of the previous epilogue).
+    int next_tile = 0;
+    auto ktile = [&](auto BUFC, auto MODEC, auto FIRSTC, int t) {
+        constexpr int BUF = decltype(BUFC)::value, MODE = decltype(MODEC)::value;
+        constexpr bool FIRST = decltype(FIRSTC)::value;
+        using Z = std::integral_constant<bool, FIRST>;
+        // ph1: (A0,B0)
+        read_b(BUF, 0);
+        read_a(BUF, 0);
+        stage_b(1, BUF ^ 1, MODE == 2 ? 0 : t + 1);
+        if constexpr (!FIRST) G8_WAIT_VM(6);
+        G8P_SECTION(0, 0, Z{});
+        // ph2: (A0,B1)
+        read_b(BUF, 1);
+        stage_a(1, BUF ^ 1, MODE == 2 ? 0 : t + 1);
+        G8P_SECTION(0, 1, Z{});
+        if constexpr (MODE == 1) set_tile(next_tile);
+        // ph3: (A1,B1)
+        read_a(BUF, 1);
+        stage_a(0, BUF, MODE == 0 ? t + 2 : (MODE == 1 ? 0 : 1));
+        G8P_SECTION(1, 1, Z{});
+        // ph4: (A1,B0)
+        stage_b(0, BUF, MODE == 0 ? t + 2 : (MODE == 1 ? 0 : 1));
+        G8_WAIT_VM(8);
+        G8P_SECTION(1, 0, Z{});
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using BT = std::true_type;
+    using BF = std::false_type;
+
+    // ---- prologue for the first tile: stage K-tile 0 whole and A_h0/B_h0 of K-tile 1
+    int lt = l;
+    int cur_tile = start + lt;
+    set_tile(cur_tile);
+    stage_a(0, 0, 0);
+    stage_b(0, 0, 0);
+    stage_b(1, 0, 0);
+    stage_a(1, 0, 0);
+    stage_a(0, 1, 1);
+    stage_b(0, 1, 1);
+    G8_WAIT_VM(4);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // team 1 runs one barrier behind team 0
+
+    for (;;) {
+        const int nlt = lt + gx;
+        const bool has_next = nlt < cnt;
+        next_tile = has_next ? start + nlt : cur_tile;  // no next tile: harmless re-prefetch of this one
+        ktile(I0{}, I0{}, BT{}, 0);
+        ktile(I1{}, I0{}, BF{}, 1);
+        for (int t = 2; t < nk - 2; t += 2) {
+            ktile(I0{}, I0{}, BF{}, t);
+            ktile(I1{}, I0{}, BF{}, t + 1);
+        }
+        ktile(I0{}, I1{}, BF{}, nk - 2);
+        ktile(I1{}, I2{}, BF{}, nk - 1);
+
+        // Both teams run the epilogue in the same barrier interval: team 0 waits one barrier
+        // before it, team 1 one barrier after it (which also restores the stagger).
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        G8_WAIT_VM(4);  // retire B_h1/A_h1 of the next tile's K-tile 0 before any epilogue traffic
+        {
+            // lane (c = lane&15, g = lane>>4): acc[ha][mi][hb][ni][j] is output row
+            // ha*128 + wr*64 + mi*16 + 4g + j, column wc*64 + 4c + (2hb + ni): 8-byte stores, 16 lanes
+            // cover one full 128-byte line of a row. Stores (and residual loads) go through buffer
+            // resources based at the tile's first row: rows >= M fall outside num_records and are
+            // dropped by the hardware range check; lanes whose columns are >= N get an offset that
+            // is always out of range. No branches.
+            const int mt = cur_tile / P.NT, nt = cur_tile - mt * P.NT;
+            const int m0 = mt * BM, n0 = nt * BN;
+            const int nb = n0 + wc * 64 + 4 * i;
+            const bool col_ok = nb < P.N;  // N % 8 == 0: 4 columns all in or all out
+            const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
+            const unsigned span = (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * 2u;
+            const __amdgpu_buffer_rsrc_t Cr =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(P.C + (size_t)m0 * P.N), 0, span, 0x00020000);
+            __amdgpu_buffer_rsrc_t Rr = Cr;
+            if constexpr (EPI == VIT_EPI_RESIDUAL)
+                Rr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.res + (size_t)m0 * P.N), 0, span, 0x00020000);
+            const unsigned voff0 = col_ok ? (unsigned)((wr * 64 + 4 * q) * P.N + nb) * 2u : 0x80000000u;
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (P.bias != nullptr && col_ok) {
+                const float4 b0 = *(const float4*)(P.bias + nb);
+                bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+            }
+            // residual tile: all 32 loads are issued up front into the (now dead) fragment registers
+            u32x2 rres[32];
+            if constexpr (EPI == VIT_EPI_RESIDUAL) {
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    const unsigned voff = voff0 + (unsigned)(((s >> 4) * 128 + ((s >> 2) & 3) * 16 + (s & 3)) * P.N) * 2u;
+                    rres[s] = __builtin_amdgcn_raw_buffer_load_b64(Rr, (int)voff, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned voff = voff0 + (unsigned)((ha * 128 + mi * 16 + j) * P.N) * 2u;
+                        float v[4];
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni)
+                                v[hb * 2 + ni] = apply_act_bf16<EPI>(acc[ha][mi][hb][ni][j] + bias[hb * 2 + ni]);
+                        if constexpr (EPI == VIT_EPI_RESIDUAL) {
+                            const bf16x4 r = __builtin_bit_cast(bf16x4, rres[ha * 16 + mi * 4 + j]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                        }
+                        bf16x4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, 0);
+                    }
+        }
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        if (!has_next) break;
+        lt = nlt;
+        cur_tile = next_tile;
+    }
+    G8_WAIT_VM(0);  // the dummy prefetch of the last tile must land before the LDS is released
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // balance team 1's extra barrier
+}
+
+template <int EPI>
+int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
+    auto kern = gemm8p_persist_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    const int G = P.T < ncu ? P.T : ncu;
+    hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), LDS_BYTES, stream, P);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+}  // namespace g8
+
+// true when the 8-phase kernel takes this problem
+bool gemm_bf16_8p_eligible(int M, int N, int K) {
+    return K % 128 == 0 && K >= 256 && N % 8 == 0 && M >= 1 && (size_t)256 * K * 2 < ((size_t)1 << 31);
+}
+
+#ifdef G8_LAB
+int g8_dbg = 0;      // lab: bit0 = timing-only build without output stores
+#endif
+int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
+                         int epi, hipStream_t stream) {
+    VIT_REQUIRE(gemm_bf16_8p_eligible(M, N, K), "gemm8pp: shape M=%d N=%d K=%d not eligible", M, N, K);
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        VIT_CHECK_HIP(hipGetDevice(&dev));
+        VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    g8::PParams P{};
+    P.A = (const bf16_t*)A; P.W = (const bf16_t*)W; P.bias = bias; P.res = (const bf16_t*)res; P.C = (bf16_t*)C;
+    P.M = M; P.N = N; P.K = K;
+    P.NT = ceil_div(N, g8::BN);
+    P.T = ceil_div(M, g8::BM) * P.NT;
+#ifdef G8_LAB
+    P.dbg = g8_dbg;
+#endif
+    switch (epi) {
+        case VIT_EPI_BIAS: return g8::launch_persist<VIT_EPI_BIAS>(P, ncu, stream);
+        case VIT_EPI_GELU: return g8::launch_persist<VIT_EPI_GELU>(P, ncu, stream);
+        case VIT_EPI_QUICK_GELU: return g8::launch_persist<VIT_EPI_QUICK_GELU>(P, ncu, stream);
+        case VIT_EPI_RESIDUAL: return g8::launch_persist<VIT_EPI_RESIDUAL>(P, ncu, stream);
+    }
+    return vit_set_error(VIT_E_INVALID, "gemm8pp: unknown epilogue %d", epi);
+}
