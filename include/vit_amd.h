@@ -50,6 +50,8 @@ extern "C" {
 #define VIT_EPI_GELU 1       /* C = gelu(A W^T + bias)                 (fc1:  MV:250-251) */
 #define VIT_EPI_QUICK_GELU 2 /* C = quick_gelu(A W^T + bias)           (CLIP fc1) */
 #define VIT_EPI_RESIDUAL 3   /* C = A W^T + bias + residual            (o_proj+res MV:236,277; fc2+res MV:252,284) */
+#define VIT_EPI_DGELU 4      /* C = (A W^T) * gelu'(aux)               (backward of MV:251; aux = fc1 pre-activation) */
+#define VIT_EPI_DQUICK_GELU 5 /* C = (A W^T) * quick_gelu'(aux)        (CLIP) */
 
 #define VIT_OK 0
 #define VIT_E_INVALID (-1)   /* bad argument / unsupported shape */
@@ -138,6 +140,38 @@ int vit_patch_embed_fwd(const void* pixels, const void* weight, const float* bia
                         const float* pos, void* x_out, int batch, int channels, int image, int patch,
                         int dim, int dtype, void* stream);
 int vit_patch_kpad(int channels, int patch, int dtype);
+
+/* ---- training-step kernels (VIT_BF16 activations, fp32 statistics and parameter gradients).
+ * The reference has no training code at all; these are the backward
+ * counterparts of the entry points above, needed by BASELINE.json configs[4]. ---- */
+
+/* vit_gemm_bias_act with the training outputs. `residual_or_aux`: residual for
+ * VIT_EPI_RESIDUAL, the fc1 pre-activation for VIT_EPI_DGELU / VIT_EPI_DQUICK_GELU (backward of
+ * MV:251: C = (A W^T) * act'(aux)). `C_pre` (may be NULL; activation epilogues only) also
+ * receives the pre-activation A W^T + bias. `out_f32` != 0 (VIT_EPI_BIAS only): C is fp32 --
+ * used for weight gradients dW = dY^T X with A = dY^T, W = X^T. bf16 mode only. */
+int vit_gemm_ex(const void* A, const void* W, const float* bias, const void* residual_or_aux, void* C, void* C_pre,
+                int M, int N, int K, int epilogue, int out_f32, void* stream);
+
+/* vit_attention_fwd that also writes lse [batch, heads, seq] fp32: log2 of the softmax
+ * denominator of the scaled scores (P = exp2(S * dh^-0.5 * log2 e - lse)). */
+int vit_attention_fwd_train(const void* qkv, void* out, float* lse, int batch, int seq, int heads, int head_dim,
+                            void* stream);
+/* Backward of eager_attention_forward (MV:164-189): dqkv [batch*seq, 3*heads*head_dim] from qkv,
+ * the forward output `out`, its gradient `d_out` and `lse`; `delta_scratch` is fp32
+ * [batch, heads, seq]. Bitwise reproducible (no atomics). */
+int vit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* delta_scratch,
+                      void* dqkv, int batch, int seq, int heads, int head_dim, void* stream);
+
+/* Backward of nn.LayerNorm (MV:261-262): dx = LN'(x)^T dy (+ d_residual if non-NULL, the
+ * gradient of the skip branch, MV:277,284); dgamma / dbeta are ACCUMULATED (+=, fp32 atomics). */
+int vit_layernorm_bwd(const void* x, const void* dy, const float* gamma, const void* d_residual, void* dx,
+                      float* dgamma, float* dbeta, int rows, int dim, float eps, void* stream);
+
+/* dst[C, Rpad] = src[R, C]^T (bf16), columns R..Rpad zero; colsum (may be NULL) += column sums of
+ * src in fp32 (bias gradients). group > 0: src is [B, group+1, C] and the first row of every
+ * group is skipped (token rows without CLS). C % 8 == 0, Rpad % 8 == 0. */
+int vit_transpose_pad(const void* src, void* dst, float* colsum, int R, int C, int Rpad, int group, void* stream);
 
 /* Elementwise dtype conversion (plumbing for weight / pixel ingestion). */
 int vit_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, void* stream);

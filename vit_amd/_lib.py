@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER, Structure
 
 VIT_F32, VIT_BF16 = 0, 1
-EPI_BIAS, EPI_GELU, EPI_QUICK_GELU, EPI_RESIDUAL = 0, 1, 2, 3
+EPI_BIAS, EPI_GELU, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_DQUICK_GELU = 0, 1, 2, 3, 4, 5
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvit_amd.so")
 
@@ -53,6 +53,14 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_void_p]),
     "vit_patch_kpad": (c_int, [c_int, c_int, c_int]),
     "vit_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "vit_gemm_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                            c_int, c_void_p]),
+    "vit_attention_fwd_train": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vit_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_void_p]),
+    "vit_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_float, c_void_p]),
+    "vit_transpose_pad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -43,7 +43,8 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
 
 template <int DH>
 __global__ __launch_bounds__(512) void attention_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                            int N, int H, int KC, float scale_log2e) {
+                                                            float* __restrict__ lse, int N, int H, int KC,
+                                                            float scale_log2e) {
     using G = AttnGeo<DH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Kl = smem;                       // [KC][KS]
@@ -80,20 +81,33 @@ __global__ __launch_bounds__(512) void attention_bf16_kernel(const bf16_t* __res
         int nkeys = N - kc0;
         nkeys = (nkeys > KC) ? KC : ((nkeys + 31) & ~31);
         __syncthreads();  // previous chunk fully consumed
-        for (int idx = tid; idx < nkeys * G::CHUNKS; idx += blockDim.x) {
-            const int key = idx / G::CHUNKS, c = idx - key * G::CHUNKS;
-            const int gk = kc0 + key;
-            bf16x8 kv, vv;
-            if (gk < N) {
-                const bf16_t* p = base + (size_t)gk * rs + c * 8;
-                kv = *(const bf16x8*)(p + D);
-                vv = *(const bf16x8*)(p + 2 * D);
-            } else {
+        // stage K/V: every thread issues a batch of 2 x SB 16-byte loads before the first LDS
+        // write, so a whole chunk's loads are in flight together (one HBM latency per chunk).
+        constexpr int SB = 4;
+        const int total = nkeys * G::CHUNKS;
+        for (int idx0 = tid; idx0 < total; idx0 += SB * blockDim.x) {
+            bf16x8 kv[SB], vv[SB];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { kv[e] = (bf16_t)0.f; vv[e] = (bf16_t)0.f; }
+            for (int u = 0; u < SB; ++u) {
+                const int idx = idx0 + u * blockDim.x;
+                const int key = idx / G::CHUNKS, c = idx - key * G::CHUNKS;
+                int gk = kc0 + key;
+                if (gk > N - 1) gk = N - 1;  // pad keys re-read the last row (their scores are masked)
+                const bf16_t* p = base + (size_t)gk * rs + c * 8;
+                if (idx < total) {
+                    kv[u] = *(const bf16x8*)(p + D);
+                    vv[u] = *(const bf16x8*)(p + 2 * D);
+                }
             }
-            *(bf16x8*)(Kl + (size_t)key * G::KS + c * 16) = kv;
-            *(bf16x8*)(Vl + (size_t)key * G::VS + c * 16) = vv;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = idx0 + u * blockDim.x;
+                const int key = idx / G::CHUNKS, c = idx - key * G::CHUNKS;
+                if (idx < total) {
+                    *(bf16x8*)(Kl + (size_t)key * G::KS + c * 16) = kv[u];
+                    *(bf16x8*)(Vl + (size_t)key * G::VS + c * 16) = vv[u];
+                }
+            }
         }
         __syncthreads();
 
@@ -122,19 +136,24 @@ __global__ __launch_bounds__(512) void attention_bf16_kernel(const bf16_t* __res
             for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx * scale_log2e);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
+            // the running max rarely moves after the first tiles: rescale O / l only when some
+            // query of the wave saw a larger score (wave-uniform branch; exact, no threshold)
+            if (__any(m_new > m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                s[e] = __builtin_amdgcn_exp2f(s[e] * scale_log2e - m_new);
+                s[e] = __builtin_amdgcn_exp2f(s[e] * scale_log2e - m_run);
                 psum += s[e];
             }
-            l_run = l_run * alpha + psum;
-#pragma unroll
-            for (int d = 0; d < G::DB; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+            l_run += psum;
 
             // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -156,6 +175,8 @@ __global__ __launch_bounds__(512) void attention_bf16_kernel(const bf16_t* __res
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    // training forward: base-2 log-sum-exp of the scaled scores, P = exp2(S c - lse) in the backward
+    if (lse != nullptr && hi == 0 && q0 + r < N) lse[((size_t)b * H + h) * N + q0 + r] = m_run + log2f(l_tot);
     if (q0 + r < N) {
         bf16_t* op = out + ((size_t)b * N + q0 + r) * D + (size_t)h * DH;
 #pragma unroll
@@ -301,7 +322,7 @@ void pick_waves(int N, int* waves, int* qblocks) {
 }
 
 template <int DH>
-int launch_attn_bf16(const void* qkv, void* out, int batch, int N, int H, hipStream_t stream) {
+int launch_attn_bf16(const void* qkv, void* out, float* lse, int batch, int N, int H, hipStream_t stream) {
     using G = AttnGeo<DH>;
     int waves, qblocks;
     pick_waves(N, &waves, &qblocks);
@@ -317,7 +338,7 @@ int launch_attn_bf16(const void* qkv, void* out, int batch, int N, int H, hipStr
     }
     const float scale_log2e = LOG2E / sqrtf((float)DH);
     hipLaunchKernelGGL(kern, dim3(batch * H, qblocks), dim3(waves * 64), lds, stream, (const bf16_t*)qkv, (bf16_t*)out,
-                       N, H, KC, scale_log2e);
+                       lse, N, H, KC, scale_log2e);
     VIT_CHECK_HIP(hipGetLastError());
     return VIT_OK;
 }
@@ -348,14 +369,15 @@ int launch_attn_f32(const void* qkv, void* out, int batch, int N, int H, hipStre
 }  // namespace
 
 int launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, int dtype,
-                     hipStream_t stream) {
+                     hipStream_t stream, float* lse) {
     VIT_REQUIRE(batch > 0 && seq > 0 && heads > 0, "attention: empty problem");
     VIT_REQUIRE(head_dim % 16 == 0 && head_dim >= 16 && head_dim <= 128,
                 "attention: head_dim must be a multiple of 16 in [16,128], got %d", head_dim);
     VIT_REQUIRE(dtype == VIT_BF16 || dtype == VIT_F32, "attention: bad dtype %d", dtype);
+    VIT_REQUIRE(lse == nullptr || dtype == VIT_BF16, "attention: the log-sum-exp output is bf16-mode only");
 #define ATTN_CASE(DHV)                                                                          \
     case DHV:                                                                                   \
-        return dtype == VIT_BF16 ? launch_attn_bf16<DHV>(qkv, out, batch, seq, heads, stream)   \
+        return dtype == VIT_BF16 ? launch_attn_bf16<DHV>(qkv, out, lse, batch, seq, heads, stream) \
                                  : launch_attn_f32<DHV>(qkv, out, batch, seq, heads, stream);
     switch (head_dim) {
         ATTN_CASE(16) ATTN_CASE(32) ATTN_CASE(48) ATTN_CASE(64) ATTN_CASE(80) ATTN_CASE(96) ATTN_CASE(112) ATTN_CASE(128)

@@ -1,0 +1,316 @@
+// Fused multi-head self-attention BACKWARD (bf16 I/O, fp32 math): gradients of
+// out = softmax(Q K^T * dh^-0.5) V (eager_attention_forward, modeling_vit.py:164-189) with
+// respect to the packed projection output qkv. No N x N matrix is ever written: P is recomputed
+// from Q, K and the forward's per-row log-sum-exp (base 2, already scaled).
+//
+//   P  = exp2(S c - L2),  S = Q K^T,  c = dh^-0.5 log2(e)
+//   dP = dO V^T,  delta = rowsum(dO * O),  dS = P * (dP - delta)
+//   dQ = dS K * dh^-0.5,   dK = dS^T Q * dh^-0.5,   dV = P^T dO
+//
+// Two launches of one kernel template, each with the OUTER index on the MFMA lane so that every
+// sum runs over accumulator rows (an accumulator tile is then directly the B operand of the next
+// product, no transposes, no atomics, bitwise reproducible):
+//   MODE_DQ : outer = 32 queries per wave (Q, dO fragments in registers), inner = keys streamed
+//             through LDS:  S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T.
+//   MODE_DKV: outer = 32 keys per wave (K, V fragments in registers), inner = queries streamed
+//             through LDS:  S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
+// Transposed operands (K^T, dO^T, Q^T) come from row-major LDS images by ds_read_b64_tr_b16.
+// S and dP are computed twice (7 instead of 5 products) -- the price of having no cross-wave
+// reduction; at N = 197 the backward is HBM/latency bound anyway (DESIGN.md "Backward").
+#include "vit_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+enum { MODE_DQ = 0, MODE_DKV = 1 };
+
+template <int DH>
+struct BGeo {
+    static constexpr int KSTEPS = DH / 16;
+    static constexpr int DB = (DH + 31) / 32;
+    static constexpr int RS = DH * 2 + 16;      // row-read image stride, bytes (conflict-free ds_read_b128)
+    static constexpr int TS = (DB | 1) * 64;    // tr-read image stride, bytes (odd multiple of 64)
+    static constexpr int CHUNKS = DH / 8;
+};
+
+__device__ __forceinline__ bf16x8 pack8b(const f32x16& p, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)p[8 * s + e];
+    return o;
+}
+
+// A^T-operand fragment (32 rows of d-block `d`, k = 16 inner rows starting at row0 + 16*sk) read
+// transposed from a row-major [inner][d] image with stride TS.
+template <int TS>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int row0, int sk, int d, int tr_key, int tr_col) {
+    const unsigned char* vp = img + (size_t)(row0 + 16 * sk + tr_key) * TS + tr_col + d * 64;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vp));
+    const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(vp + 8 * TS));
+    const short8v both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+template <int DH, int MODE>
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                       const float* __restrict__ lse, const float* __restrict__ delta,
+                                                       bf16_t* __restrict__ dqkv, int N, int H, int IC, float scale_log2e,
+                                                       float scale) {
+    using G = BGeo<DH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // inner-operand images: I1 = K (DQ) / Q (DKV), I2 = V (DQ) / dO (DKV)
+    unsigned char* R1 = smem;                          // [IC][RS] row image of I1
+    unsigned char* R2 = R1 + (size_t)IC * G::RS;       // [IC][RS] row image of I2
+    unsigned char* T1 = R2 + (size_t)IC * G::RS;       // [IC][TS] tr image of I1
+    unsigned char* T2 = T1 + (size_t)IC * G::TS;       // [IC][TS] tr image of I2 (DKV only)
+    float* rowL = (float*)(T2 + (MODE == MODE_DKV ? (size_t)IC * G::TS : 0));  // [IC] L2 of inner queries (DKV)
+    float* rowD = rowL + IC;                                                   // [IC] delta of inner queries (DKV)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * DH;
+    const size_t rs = (size_t)3 * D;
+    const bf16_t* qbase = qkv + (size_t)b * N * rs + (size_t)h * DH;          // q | k (+D) | v (+2D)
+    const bf16_t* dobase = dO + (size_t)b * N * D + (size_t)h * DH;
+    const float* lrow = lse + ((size_t)b * H + h) * N;
+    const float* drow = delta + ((size_t)b * H + h) * N;
+
+    // ---- outer fragments (B operands): lane&31 = outer row, 8 consecutive d of half hi per k-step
+    const int o0 = (blockIdx.y * nwaves + wave) * 32;
+    const int orow = (o0 + r < N) ? o0 + r : N - 1;
+    bf16x8 f1[G::KSTEPS], f2[G::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        if constexpr (MODE == MODE_DQ) {
+            f1[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + ks * 16 + hi * 8);             // Q
+            f2[ks] = *(const bf16x8*)(dobase + (size_t)orow * D + ks * 16 + hi * 8);             // dO
+        } else {
+            f1[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + D + ks * 16 + hi * 8);         // K
+            f2[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + 2 * D + ks * 16 + hi * 8);     // V
+        }
+    }
+    float oL = 0.f, oD = 0.f;  // DQ: per-lane query constants
+    if constexpr (MODE == MODE_DQ) {
+        oL = lrow[orow];
+        oD = drow[orow];
+    }
+
+    f32x16 acc1[G::DB], acc2[G::DB];  // DQ: acc1 = dQ^T.  DKV: acc1 = dK^T, acc2 = dV^T
+#pragma unroll
+    for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc1[d][e] = 0.f; acc2[d][e] = 0.f; }
+
+    const int g = lane >> 4, i16 = lane & 15;
+    const int tr_key = 4 * (g >> 1) + (i16 >> 2);
+    const int tr_col = ((g & 1) * 16 + 4 * (i16 & 3)) * 2;
+
+    for (int ic0 = 0; ic0 < N; ic0 += IC) {
+        int nin = N - ic0;
+        nin = (nin > IC) ? IC : ((nin + 31) & ~31);
+        __syncthreads();
+        // ---- stage the inner rows (pad rows re-read the last row; they are masked below)
+        const int total = nin * G::CHUNKS;
+        for (int idx = tid; idx < total; idx += blockDim.x) {
+            const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+            int gr = ic0 + row;
+            if (gr > N - 1) gr = N - 1;
+            bf16x8 v1, v2;
+            if constexpr (MODE == MODE_DQ) {
+                const bf16_t* p = qbase + (size_t)gr * rs + c * 8;
+                v1 = *(const bf16x8*)(p + D);       // K
+                v2 = *(const bf16x8*)(p + 2 * D);   // V
+            } else {
+                v1 = *(const bf16x8*)(qbase + (size_t)gr * rs + c * 8);      // Q
+                v2 = *(const bf16x8*)(dobase + (size_t)gr * D + c * 8);     // dO
+            }
+            *(bf16x8*)(R1 + (size_t)row * G::RS + c * 16) = v1;
+            *(bf16x8*)(R2 + (size_t)row * G::RS + c * 16) = v2;
+            *(bf16x8*)(T1 + (size_t)row * G::TS + c * 16) = v1;
+            if constexpr (MODE == MODE_DKV) *(bf16x8*)(T2 + (size_t)row * G::TS + c * 16) = v2;
+        }
+        if constexpr (MODE == MODE_DKV) {
+            for (int row = tid; row < nin; row += blockDim.x) {
+                const int gr = ic0 + row;
+                rowL[row] = gr < N ? lrow[gr] : INFINITY;  // P = exp2(.. - inf) = 0 for pad queries
+                rowD[row] = gr < N ? drow[gr] : 0.f;
+            }
+        }
+        __syncthreads();
+
+        const int ntiles = nin >> 5;
+        for (int t = 0; t < ntiles; ++t) {
+            // ---- S tile and dP tile: rows = 32 inner rows (registers), col = outer row (lane)
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+            const unsigned char* p1 = R1 + (size_t)(t * 32 + r) * G::RS + hi * 16;
+            const unsigned char* p2 = R2 + (size_t)(t * 32 + r) * G::RS + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < G::KSTEPS; ++ks) {
+                const bf16x8 a1 = *(const bf16x8*)(p1 + ks * 32);
+                const bf16x8 a2 = *(const bf16x8*)(p2 + ks * 32);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, f1[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, f2[ks], dp, 0, 0, 0);
+            }
+            // ---- P and dS in place (register e is inner row (e&3) + 8(e>>2) + 4hi of the tile)
+            if constexpr (MODE == MODE_DQ) {
+                const int key0 = ic0 + t * 32;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    const float p = (key < N) ? __builtin_amdgcn_exp2f(s[e] * scale_log2e - oL) : 0.f;
+                    s[e] = p * (dp[e] - oD);  // dS^T
+                }
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 L = *(const f32x4*)(rowL + t * 32 + 8 * g4 + 4 * hi);
+                    const f32x4 Dl = *(const f32x4*)(rowD + t * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = g4 * 4 + j;
+                        const float p = __builtin_amdgcn_exp2f(s[e] * scale_log2e - L[j]);
+                        dp[e] = p * (dp[e] - Dl[j]);  // dS
+                        s[e] = p;                     // P
+                    }
+                }
+            }
+            // ---- accumulate: sums over the 32 inner rows (two k-steps of 16)
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                if constexpr (MODE == MODE_DQ) {
+                    const bf16x8 dsb = pack8b(s, sk);
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d)
+                        acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<G::TS>(T1, t * 32, sk, d, tr_key, tr_col), dsb,
+                                                                          acc1[d], 0, 0, 0);  // dQ^T += K^T dS^T
+                } else {
+                    const bf16x8 pb = pack8b(s, sk), dsb = pack8b(dp, sk);
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d) {
+                        acc2[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<G::TS>(T2, t * 32, sk, d, tr_key, tr_col), pb,
+                                                                          acc2[d], 0, 0, 0);  // dV^T += dO^T P
+                        acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<G::TS>(T1, t * 32, sk, d, tr_key, tr_col), dsb,
+                                                                          acc1[d], 0, 0, 0);  // dK^T += Q^T dS
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- store: lane = outer row, registers = d (4 consecutive per group)
+    if (o0 + r < N) {
+        bf16_t* op = dqkv + ((size_t)b * N + o0 + r) * rs + (size_t)h * DH + (MODE == MODE_DKV ? D : 0);
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = d * 32 + 8 * g4 + 4 * hi;
+                if (d0 < DH) {
+                    bf16x4 v1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v1[e] = (bf16_t)(acc1[d][g4 * 4 + e] * scale);
+                    *(bf16x4*)(op + d0) = v1;  // dQ (DQ) or dK (DKV)
+                    if constexpr (MODE == MODE_DKV) {
+                        bf16x4 v2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v2[e] = (bf16_t)acc2[d][g4 * 4 + e];
+                        *(bf16x4*)(op + D + d0) = v2;  // dV
+                    }
+                }
+            }
+    }
+}
+
+// delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]
+template <int DH>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
+                                                         float* __restrict__ delta, int B, int N, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // over B * N * H, head fastest
+    if (idx >= B * N * H) return;
+    const int h = idx % H, row = idx / H;            // row = b * N + q
+    const bf16_t* o = O + (size_t)row * H * DH + (size_t)h * DH;
+    const bf16_t* g = dO + (size_t)row * H * DH + (size_t)h * DH;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) {
+        const bf16x8 a = *(const bf16x8*)(o + c * 8), bb = *(const bf16x8*)(g + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)bb[e];
+    }
+    const int b = row / N, q = row - b * N;
+    delta[((size_t)b * H + h) * N + q] = s;
+}
+
+void pick_waves_b(int N, int* waves, int* blocks) {
+    const int n32 = ceil_div(N, 32);
+    int best_w = 1, best_cost = 1 << 30;
+    for (int w = 8; w >= 1; --w) {
+        if (w < 4 && n32 >= 4) break;
+        const int cost = ceil_div(n32, w) * w;
+        if (cost < best_cost) { best_cost = cost; best_w = w; }
+    }
+    *waves = best_w;
+    *blocks = ceil_div(n32, best_w);
+}
+
+template <int DH, int MODE>
+int launch_bwd_part(const void* qkv, const void* dO, const float* lse, const float* delta, void* dqkv, int batch, int N,
+                    int H, hipStream_t stream) {
+    using G = BGeo<DH>;
+    constexpr int per_row = 2 * G::RS + (MODE == MODE_DKV ? 2 : 1) * G::TS + (MODE == MODE_DKV ? 8 : 0);
+    constexpr int LDS_MAX = 64 * 1024;
+    int waves, blocks;
+    pick_waves_b(N, &waves, &blocks);
+    int icmax = (LDS_MAX / per_row) / 32 * 32;
+    int IC = ((N + 31) / 32) * 32;
+    if (IC > icmax) IC = icmax;
+    const size_t lds = (size_t)IC * per_row;
+    auto kern = attn_bwd_kernel<DH, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+        attr_set = true;
+    }
+    const float scale = 1.0f / sqrtf((float)DH);
+    hipLaunchKernelGGL(kern, dim3(batch * H, blocks), dim3(waves * 64), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dO,
+                       lse, delta, (bf16_t*)dqkv, N, H, IC, scale * LOG2E, scale);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+template <int DH>
+int launch_bwd(const void* qkv, const void* O, const void* dO, const float* lse, float* delta, void* dqkv, int batch,
+               int N, int H, hipStream_t stream) {
+    const int total = batch * N * H;
+    hipLaunchKernelGGL(attn_delta_kernel<DH>, dim3(ceil_div(total, 256)), dim3(256), 0, stream, (const bf16_t*)O,
+                       (const bf16_t*)dO, delta, batch, N, H);
+    VIT_CHECK_HIP(hipGetLastError());
+    int rc = launch_bwd_part<DH, MODE_DQ>(qkv, dO, lse, delta, dqkv, batch, N, H, stream);
+    if (rc != VIT_OK) return rc;
+    return launch_bwd_part<DH, MODE_DKV>(qkv, dO, lse, delta, dqkv, batch, N, H, stream);
+}
+
+}  // namespace
+
+// qkv [B*N, 3D] packed projection output, O [B*N, D] forward attention output, dO its gradient,
+// lse [B, H, N] fp32 (base-2 log-sum-exp of the scaled scores, from the training forward),
+// delta [B, H, N] fp32 scratch, dqkv [B*N, 3D] output.
+int launch_attention_bwd(const void* qkv, const void* O, const void* dO, const float* lse, float* delta, void* dqkv,
+                         int batch, int seq, int heads, int head_dim, hipStream_t stream) {
+    VIT_REQUIRE(batch > 0 && seq > 0 && heads > 0, "attention_bwd: empty problem");
+    VIT_REQUIRE(head_dim % 16 == 0 && head_dim >= 16 && head_dim <= 128,
+                "attention_bwd: head_dim must be a multiple of 16 in [16,128], got %d", head_dim);
+#define ATTNB_CASE(DHV) \
+    case DHV: return launch_bwd<DHV>(qkv, O, dO, lse, delta, dqkv, batch, seq, heads, stream);
+    switch (head_dim) {
+        ATTNB_CASE(16) ATTNB_CASE(32) ATTNB_CASE(48) ATTNB_CASE(64) ATTNB_CASE(80) ATTNB_CASE(96) ATTNB_CASE(112) ATTNB_CASE(128)
+    }
+#undef ATTNB_CASE
+    return vit_set_error(VIT_E_INVALID, "attention_bwd: unsupported head_dim %d", head_dim);
+}

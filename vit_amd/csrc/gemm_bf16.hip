@@ -38,7 +38,9 @@ struct GemmParams {
     const bf16_t* W;
     const float* bias;
     const bf16_t* res;
-    bf16_t* C;
+    bf16_t* C;      // bf16 output, or fp32 output when out_f32
+    bf16_t* Cpre;   // optional second output: pre-activation (activation epilogues)
+    int out_f32;
     const float* pos;
     int M, N, K;
     int NT;  // tiles along N
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const GemmParams
 #pragma unroll
         for (int b = 0; b < G::NI; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[b * 4 + j] = apply_act_bf16<EPI>(acc[a][b][j] + bias[b * 4 + j]);
+            for (int j = 0; j < 4; ++j) v[b * 4 + j] = acc[a][b][j] + bias[b * 4 + j];
         size_t orow = (size_t)m;
         if constexpr (EPI == EPI_PATCH) {
             const int bimg = m / np, pr = m - bimg * np + 1;  // token index inside the image (CLS = 0)
@@ -238,15 +240,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const GemmParams
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (nb + h * 8 >= P.N) continue;
-            if constexpr (EPI == VIT_EPI_RESIDUAL) {
-                const bf16x8 r = *(const bf16x8*)(P.res + orow * P.N + nb + h * 8);
+            const size_t o = orow * P.N + nb + h * 8;
+            if constexpr (EPI == VIT_EPI_GELU || EPI == VIT_EPI_QUICK_GELU) {
+                if (P.Cpre != nullptr) {
+                    bf16x8 pv;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[h * 8 + e] += (float)r[e];
+                    for (int e = 0; e < 8; ++e) pv[e] = (bf16_t)v[h * 8 + e];
+                    *(bf16x8*)(P.Cpre + o) = pv;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[h * 8 + e] = apply_act_bf16<EPI>(v[h * 8 + e]);
             }
-            bf16x8 o;
+            if constexpr (EPI == VIT_EPI_RESIDUAL || EPI == VIT_EPI_DGELU || EPI == VIT_EPI_DQUICK_GELU) {
+                const bf16x8 r = *(const bf16x8*)(P.res + o);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[h * 8 + e];
-            *(bf16x8*)(P.C + orow * P.N + nb + h * 8) = o;
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (EPI == VIT_EPI_RESIDUAL) v[h * 8 + e] += (float)r[e];
+                    else v[h * 8 + e] *= act_grad<EPI>((float)r[e]);
+                }
+            }
+            if (P.out_f32) {
+                float* cf = (float*)P.C + o;
+                *(f32x4*)cf = f32x4{v[h * 8 + 0], v[h * 8 + 1], v[h * 8 + 2], v[h * 8 + 3]};
+                *(f32x4*)(cf + 4) = f32x4{v[h * 8 + 4], v[h * 8 + 5], v[h * 8 + 6], v[h * 8 + 7]};
+            } else {
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[h * 8 + e];
+                *(bf16x8*)(P.C + o) = ov;
+            }
         }
     }
 }
@@ -277,6 +299,8 @@ int dispatch_epi(const GemmParams& P, int epi, hipStream_t stream) {
             case VIT_EPI_GELU: return launch_one<BN, AMODE, VIT_EPI_GELU>(P, stream);
             case VIT_EPI_QUICK_GELU: return launch_one<BN, AMODE, VIT_EPI_QUICK_GELU>(P, stream);
             case VIT_EPI_RESIDUAL: return launch_one<BN, AMODE, VIT_EPI_RESIDUAL>(P, stream);
+            case VIT_EPI_DGELU: return launch_one<BN, AMODE, VIT_EPI_DGELU>(P, stream);
+            case VIT_EPI_DQUICK_GELU: return launch_one<BN, AMODE, VIT_EPI_DQUICK_GELU>(P, stream);
         }
         return vit_set_error(VIT_E_INVALID, "gemm: unknown epilogue %d", epi);
     }
@@ -298,29 +322,35 @@ int pick_bn(int M, int N) {
 
 bool gemm_bf16_8p_eligible(int M, int N, int K);
 int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
-                        int epi, hipStream_t stream);
+                        int epi, const GemmExt* ext, hipStream_t stream);
 
 // generic tile kernel of this file (any K % 8 == 0, patch loaders); also the lab's baseline
 int launch_gemm_bf16_generic(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N,
-                             int K, int epi, const PatchGeom* patch, const float* pos, hipStream_t stream);
+                             int K, int epi, const PatchGeom* patch, const float* pos, hipStream_t stream,
+                             const GemmExt* ext = nullptr);
 
 int launch_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
-                     int epi, const PatchGeom* patch, const float* pos, hipStream_t stream) {
+                     int epi, const PatchGeom* patch, const float* pos, hipStream_t stream, const GemmExt* ext) {
     VIT_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     VIT_REQUIRE(K % 8 == 0 && N % 8 == 0, "gemm(bf16): K and N must be multiples of 8 (K=%d N=%d)", K, N);
-    VIT_REQUIRE(epi != VIT_EPI_RESIDUAL || res != nullptr, "gemm: residual epilogue without residual");
+    VIT_REQUIRE((epi != VIT_EPI_RESIDUAL && epi != VIT_EPI_DGELU && epi != VIT_EPI_DQUICK_GELU) || res != nullptr,
+                "gemm: epilogue %d needs the residual / pre-activation operand", epi);
     // big Linear layers go to the persistent deep-pipelined kernel (gemm_bf16_8p.hip); tiny
     // problems (less than one 256x256 tile of work per 4 CUs) and K tails stay here
     if (patch == nullptr && gemm_bf16_8p_eligible(M, N, K) && (long)M * N >= 64L * 256 * 256)
-        return launch_gemm_bf16_8p(A, W, bias, res, C, M, N, K, epi, stream);
-    return launch_gemm_bf16_generic(A, W, bias, res, C, M, N, K, epi, patch, pos, stream);
+        return launch_gemm_bf16_8p(A, W, bias, res, C, M, N, K, epi, ext, stream);
+    return launch_gemm_bf16_generic(A, W, bias, res, C, M, N, K, epi, patch, pos, stream, ext);
 }
 
 int launch_gemm_bf16_generic(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N,
-                             int K, int epi, const PatchGeom* patch, const float* pos, hipStream_t stream) {
+                             int K, int epi, const PatchGeom* patch, const float* pos, hipStream_t stream,
+                             const GemmExt* ext) {
     GemmParams P{};
     P.A = (const bf16_t*)A; P.W = (const bf16_t*)W; P.bias = bias; P.res = (const bf16_t*)res; P.C = (bf16_t*)C;
     P.pos = pos; P.M = M; P.N = N; P.K = K;
+    P.Cpre = ext ? (bf16_t*)ext->c_pre : nullptr;
+    P.out_f32 = ext ? ext->out_f32 : 0;
+    VIT_REQUIRE(!P.out_f32 || (epi == VIT_EPI_BIAS && !patch), "gemm: fp32 output only with the plain epilogue");
     const int bn = pick_bn(M, N);
     P.NT = ceil_div(N, bn);
     if (patch) {

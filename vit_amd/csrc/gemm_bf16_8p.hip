@@ -44,6 +44,7 @@
 namespace g8 {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
 constexpr int HALF_BYTES = 128 * BK * 2;        // 16 KiB
@@ -71,14 +72,18 @@ struct PParams {
     const bf16_t* W;
     const float* bias;
     const bf16_t* res;
-    bf16_t* C;
+    bf16_t* C;       // bf16 output (OUTM 0, 2) or, reinterpreted, the fp32 output (OUTM 1)
+    bf16_t* Cpre;    // OUTM 2: second output, the pre-activation A W^T + bias (training forward)
     int M, N, K;
     int NT;      // tiles along N
     int T;       // total tiles
     int dbg;     // lab only (G8_LAB): bit0 = timing-only run without output stores
 };
 
-template <int EPI>
+// EPI: VIT_EPI_* ; for VIT_EPI_DGELU / VIT_EPI_DQUICK_GELU `res` is the pre-activation the
+// gradient is multiplied with. OUTM: 0 = bf16 C, 1 = fp32 C (weight gradients), 2 = bf16 C plus
+// the pre-activation in Cpre.
+template <int EPI, int OUTM>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -265,21 +270,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             const int nb = n0 + wc * 64 + 4 * i;
             const bool col_ok = nb < P.N;  // N % 8 == 0: 4 columns all in or all out
             const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
+            constexpr bool USES_RES = (EPI == VIT_EPI_RESIDUAL || EPI == VIT_EPI_DGELU || EPI == VIT_EPI_DQUICK_GELU);
+            constexpr unsigned OES = (OUTM == 1) ? 4u : 2u;  // output element size
             const unsigned span = (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * 2u;
-            const __amdgpu_buffer_rsrc_t Cr =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(P.C + (size_t)m0 * P.N), 0, span, 0x00020000);
-            __amdgpu_buffer_rsrc_t Rr = Cr;
-            if constexpr (EPI == VIT_EPI_RESIDUAL)
+            const __amdgpu_buffer_rsrc_t Cr = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((char*)P.C + (size_t)m0 * P.N * OES), 0, (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * OES,
+                0x00020000);
+            __amdgpu_buffer_rsrc_t Rr = Cr, Pr = Cr;
+            if constexpr (USES_RES)
                 Rr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.res + (size_t)m0 * P.N), 0, span, 0x00020000);
+            if constexpr (OUTM == 2)
+                Pr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.Cpre + (size_t)m0 * P.N), 0, span, 0x00020000);
             const unsigned voff0 = col_ok ? (unsigned)((wr * 64 + 4 * q) * P.N + nb) * 2u : 0x80000000u;
             float bias[4] = {0.f, 0.f, 0.f, 0.f};
             if (P.bias != nullptr && col_ok) {
                 const float4 b0 = *(const float4*)(P.bias + nb);
                 bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
             }
-            // residual tile: all 32 loads are issued up front into the (now dead) fragment registers
+            // residual / aux tile: all 32 loads are issued up front into the (now dead) fragment registers
             u32x2 rres[32];
-            if constexpr (EPI == VIT_EPI_RESIDUAL) {
+            if constexpr (USES_RES) {
 #pragma unroll
                 for (int s = 0; s < 32; ++s) {
                     const unsigned voff = voff0 + (unsigned)(((s >> 4) * 128 + ((s >> 2) & 3) * 16 + (s & 3)) * P.N) * 2u;
@@ -297,17 +307,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
 #pragma unroll
                         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                            for (int ni = 0; ni < 2; ++ni)
-                                v[hb * 2 + ni] = apply_act_bf16<EPI>(acc[ha][mi][hb][ni][j] + bias[hb * 2 + ni]);
-                        if constexpr (EPI == VIT_EPI_RESIDUAL) {
+                            for (int ni = 0; ni < 2; ++ni) v[hb * 2 + ni] = acc[ha][mi][hb][ni][j] + bias[hb * 2 + ni];
+                        if constexpr (OUTM == 2) {
+                            bf16x4 pv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pv[e] = (bf16_t)v[e];
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pv), Pr, (int)voff, 0, 0);
+                        }
+                        if constexpr (EPI == VIT_EPI_GELU || EPI == VIT_EPI_QUICK_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = apply_act_bf16<EPI>(v[e]);
+                        }
+                        if constexpr (USES_RES) {
                             const bf16x4 r = __builtin_bit_cast(bf16x4, rres[ha * 16 + mi * 4 + j]);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                            for (int e = 0; e < 4; ++e) {
+                                if constexpr (EPI == VIT_EPI_RESIDUAL) v[e] += (float)r[e];
+                                else v[e] *= act_grad<EPI>((float)r[e]);
+                            }
                         }
-                        bf16x4 ov;
+                        if constexpr (OUTM == 1) {
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                                                                         __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])},
+                                                                   Cr, (int)(voff * 2u), 0, 0);
+                        } else {
+                            bf16x4 ov;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, 0);
+                            for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, 0);
+                        }
                     }
         }
         if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -319,9 +347,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance team 1's extra barrier
 }
 
-template <int EPI>
+template <int EPI, int OUTM>
 int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
-    auto kern = gemm8p_persist_kernel<EPI>;
+    auto kern = gemm8p_persist_kernel<EPI, OUTM>;
     static bool attr_set = false;
     if (!attr_set) {
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -344,8 +372,8 @@ bool gemm_bf16_8p_eligible(int M, int N, int K) {
 int g8_dbg = 0;      // lab: bit0 = timing-only build without output stores
 #endif
 int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
-                         int epi, hipStream_t stream) {
-    VIT_REQUIRE(gemm_bf16_8p_eligible(M, N, K), "gemm8pp: shape M=%d N=%d K=%d not eligible", M, N, K);
+                        int epi, const GemmExt* ext, hipStream_t stream) {
+    VIT_REQUIRE(gemm_bf16_8p_eligible(M, N, K), "gemm8p: shape M=%d N=%d K=%d not eligible", M, N, K);
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
@@ -354,17 +382,26 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
     }
     g8::PParams P{};
     P.A = (const bf16_t*)A; P.W = (const bf16_t*)W; P.bias = bias; P.res = (const bf16_t*)res; P.C = (bf16_t*)C;
+    P.Cpre = ext ? (bf16_t*)ext->c_pre : nullptr;
     P.M = M; P.N = N; P.K = K;
     P.NT = ceil_div(N, g8::BN);
     P.T = ceil_div(M, g8::BM) * P.NT;
 #ifdef G8_LAB
     P.dbg = g8_dbg;
 #endif
+    const bool f32out = ext && ext->out_f32;
+    const bool pre = P.Cpre != nullptr;
+    VIT_REQUIRE(!(f32out && (epi != VIT_EPI_BIAS || pre)), "gemm8p: fp32 output only with the plain epilogue");
+    VIT_REQUIRE(!pre || epi == VIT_EPI_GELU || epi == VIT_EPI_QUICK_GELU, "gemm8p: pre-activation output needs an activation epilogue");
+    VIT_REQUIRE((size_t)256 * N * (f32out ? 4 : 2) < ((size_t)1 << 31), "gemm8p: N too large");
+    if (f32out) return g8::launch_persist<VIT_EPI_BIAS, 1>(P, ncu, stream);
     switch (epi) {
-        case VIT_EPI_BIAS: return g8::launch_persist<VIT_EPI_BIAS>(P, ncu, stream);
-        case VIT_EPI_GELU: return g8::launch_persist<VIT_EPI_GELU>(P, ncu, stream);
-        case VIT_EPI_QUICK_GELU: return g8::launch_persist<VIT_EPI_QUICK_GELU>(P, ncu, stream);
-        case VIT_EPI_RESIDUAL: return g8::launch_persist<VIT_EPI_RESIDUAL>(P, ncu, stream);
+        case VIT_EPI_BIAS: return g8::launch_persist<VIT_EPI_BIAS, 0>(P, ncu, stream);
+        case VIT_EPI_GELU: return pre ? g8::launch_persist<VIT_EPI_GELU, 2>(P, ncu, stream) : g8::launch_persist<VIT_EPI_GELU, 0>(P, ncu, stream);
+        case VIT_EPI_QUICK_GELU: return pre ? g8::launch_persist<VIT_EPI_QUICK_GELU, 2>(P, ncu, stream) : g8::launch_persist<VIT_EPI_QUICK_GELU, 0>(P, ncu, stream);
+        case VIT_EPI_RESIDUAL: return g8::launch_persist<VIT_EPI_RESIDUAL, 0>(P, ncu, stream);
+        case VIT_EPI_DGELU: return g8::launch_persist<VIT_EPI_DGELU, 0>(P, ncu, stream);
+        case VIT_EPI_DQUICK_GELU: return g8::launch_persist<VIT_EPI_DQUICK_GELU, 0>(P, ncu, stream);
     }
-    return vit_set_error(VIT_E_INVALID, "gemm8pp: unknown epilogue %d", epi);
+    return vit_set_error(VIT_E_INVALID, "gemm8p: unknown epilogue %d", epi);
 }

@@ -13,7 +13,7 @@
 #include <vector>
 
 int launch_gemm_bf16(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
-                     int epi, const PatchGeom* patch, const float* pos, hipStream_t stream);
+                     int epi, const PatchGeom* patch, const float* pos, hipStream_t stream, const GemmExt* ext);
 int launch_gemm_f32(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
                     int epi, const PatchGeom* patch, const float* pos, hipStream_t stream);
 int launch_convert_2d(const void* src, int sdt, void* dst, int ddt, int64_t rows, int64_t cols, int64_t dst_pitch,
@@ -31,9 +31,13 @@ int vit_set_error(int code, const char* fmt, ...) {
 }
 
 int launch_gemm(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K, int epi,
-                int dtype, const PatchGeom* patch, const float* pos, hipStream_t stream) {
-    if (dtype == VIT_BF16) return launch_gemm_bf16(A, W, bias, res, C, M, N, K, epi, patch, pos, stream);
-    if (dtype == VIT_F32) return launch_gemm_f32(A, W, bias, res, C, M, N, K, epi, patch, pos, stream);
+                int dtype, const PatchGeom* patch, const float* pos, hipStream_t stream, const GemmExt* ext) {
+    if (dtype == VIT_BF16) return launch_gemm_bf16(A, W, bias, res, C, M, N, K, epi, patch, pos, stream, ext);
+    if (dtype == VIT_F32) {
+        if (ext && (ext->c_pre || ext->out_f32) ) return vit_set_error(VIT_E_INVALID, "gemm: training outputs are bf16-mode only");
+        if (epi > VIT_EPI_RESIDUAL) return vit_set_error(VIT_E_INVALID, "gemm: backward epilogues are bf16-mode only");
+        return launch_gemm_f32(A, W, bias, res, C, M, N, K, epi, patch, pos, stream);
+    }
     return vit_set_error(VIT_E_INVALID, "gemm: bad dtype %d", dtype);
 }
 
@@ -387,6 +391,7 @@ extern "C" int vit_gemm_bias_act(const void* A, const void* W, const float* bias
                                  int N, int K, int epilogue, int dtype, void* stream) {
     VIT_REQUIRE(A && W && C, "vit_gemm_bias_act: null argument");
     VIT_REQUIRE(epilogue >= VIT_EPI_BIAS && epilogue <= VIT_EPI_RESIDUAL, "vit_gemm_bias_act: bad epilogue %d", epilogue);
+    VIT_REQUIRE(epilogue != VIT_EPI_RESIDUAL || residual != nullptr, "vit_gemm_bias_act: residual epilogue without residual");
     return launch_gemm(A, W, bias, residual, C, M, N, K, epilogue, dtype, nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -412,4 +417,41 @@ extern "C" int vit_patch_embed_fwd(const void* pixels, const void* weight, const
 extern "C" int vit_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, void* stream) {
     VIT_REQUIRE(src && dst, "vit_convert: null argument");
     return launch_convert(src, src_dtype, dst, dst_dtype, numel, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- training-step entry points
+extern "C" int vit_gemm_ex(const void* A, const void* W, const float* bias, const void* residual_or_aux, void* C,
+                           void* C_pre, int M, int N, int K, int epilogue, int out_f32, void* stream) {
+    VIT_REQUIRE(A && W && C, "vit_gemm_ex: null argument");
+    VIT_REQUIRE(epilogue >= VIT_EPI_BIAS && epilogue <= VIT_EPI_DQUICK_GELU, "vit_gemm_ex: bad epilogue %d", epilogue);
+    GemmExt ext{C_pre, out_f32};
+    return launch_gemm(A, W, bias, residual_or_aux, C, M, N, K, epilogue, VIT_BF16, nullptr, nullptr, (hipStream_t)stream,
+                       &ext);
+}
+
+extern "C" int vit_attention_fwd_train(const void* qkv, void* out, float* lse, int batch, int seq, int heads,
+                                       int head_dim, void* stream) {
+    VIT_REQUIRE(qkv && out && lse, "vit_attention_fwd_train: null argument");
+    return launch_attention(qkv, out, batch, seq, heads, head_dim, VIT_BF16, (hipStream_t)stream, lse);
+}
+
+extern "C" int vit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse,
+                                 float* delta_scratch, void* dqkv, int batch, int seq, int heads, int head_dim,
+                                 void* stream) {
+    VIT_REQUIRE(qkv && out && d_out && lse && delta_scratch && dqkv, "vit_attention_bwd: null argument");
+    return launch_attention_bwd(qkv, out, d_out, lse, delta_scratch, dqkv, batch, seq, heads, head_dim,
+                                (hipStream_t)stream);
+}
+
+extern "C" int vit_layernorm_bwd(const void* x, const void* dy, const float* gamma, const void* d_residual, void* dx,
+                                 float* dgamma, float* dbeta, int rows, int dim, float eps, void* stream) {
+    VIT_REQUIRE(x && dy && gamma && dx && dgamma && dbeta, "vit_layernorm_bwd: null argument");
+    return launch_layernorm_bwd(x, dy, gamma, d_residual, dx, dgamma, dbeta, rows, dim, dim, dim, dim, eps,
+                                (hipStream_t)stream);
+}
+
+extern "C" int vit_transpose_pad(const void* src, void* dst, float* colsum, int R, int C, int Rpad, int group,
+                                 void* stream) {
+    VIT_REQUIRE(src && dst, "vit_transpose_pad: null argument");
+    return launch_transpose_pad(src, dst, colsum, R, C, Rpad, group, (hipStream_t)stream);
 }

@@ -54,6 +54,30 @@ __device__ __forceinline__ float act_gelu_as(float x) {
     return fmaxf(x, 0.0f) - ax * p;
 }
 
+// gelu'(x) = Phi(x) + x phi(x), same erfc approximation (backward of ViTMLP's activation)
+__device__ __forceinline__ float act_dgelu_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    p = p * t * e;                                  // 0.5 erfc(|x|/sqrt2) = Phi(-|x|)
+    const float cdf = x > 0.f ? 1.0f - p : p;
+    return fmaf(x * e, 0.3989422804014327f, cdf);
+}
+__device__ __forceinline__ float act_dquick_gelu(float x) {
+    const float sg = 1.0f / (1.0f + __expf(-1.702f * x));
+    return sg * (1.0f + 1.702f * x * (1.0f - sg));
+}
+// multiplier of the backward epilogues: d act(aux) / d aux
+template <int EPI>
+__device__ __forceinline__ float act_grad(float aux) {
+    if constexpr (EPI == VIT_EPI_DGELU) return act_dgelu_as(aux);
+    else return act_dquick_gelu(aux);
+}
+
 // activations of the bf16 kernels (fp32 parity mode keeps erff)
 template <int EPI>
 __device__ __forceinline__ float apply_act_bf16(float v) {
@@ -85,12 +109,32 @@ struct PatchGeom {  // im2col-free A operand of the patch-embedding GEMM
     int kreal;                         // C*P*P (k >= kreal reads as zero)
 };
 
+// optional GEMM outputs used by the training path (bf16 kernels only)
+struct GemmExt {
+    void* c_pre;   // activation epilogues: also store the pre-activation A W^T + bias here (bf16 [M,N])
+    int out_f32;   // plain epilogue: C is fp32 [M,N] (weight gradients)
+};
+
 // C = epi(A W^T + bias (+res)); `patch` non-null => A is the pixel tensor, rows are patches,
-// output rows are remapped past the CLS slot and `pos` (fp32 [N,D]) is added.
+// output rows are remapped past the CLS slot and `pos` (fp32 [N,D]) is added. For the
+// VIT_EPI_D* epilogues `res` is the pre-activation the gradient is multiplied with.
 int launch_gemm(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
-                int epi, int dtype, const PatchGeom* patch, const float* pos, hipStream_t stream);
+                int epi, int dtype, const PatchGeom* patch, const float* pos, hipStream_t stream,
+                const GemmExt* ext = nullptr);
 int launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, int dtype,
-                     hipStream_t stream);
+                     hipStream_t stream, float* lse = nullptr);
+// training-step kernels (train_ops.hip, attention_bwd.hip); bf16 activations
+int launch_attention_bwd(const void* qkv, const void* O, const void* dO, const float* lse, float* delta, void* dqkv,
+                         int batch, int seq, int heads, int head_dim, hipStream_t stream);
+int launch_transpose_pad(const void* src, void* dst, float* colsum, int R, int C, int Rpad, int group,
+                         hipStream_t stream);
+int launch_layernorm_bwd(const void* x, const void* dy, const float* gamma, const void* dres, void* dx, float* dgamma,
+                         float* dbeta, int rows, int dim, int64_t xs, int64_t dys, int64_t dxs, float eps,
+                         hipStream_t stream);
+int launch_embed_grad(const void* dx0, float* dpos, float* dcls, int B, int N, int D, hipStream_t stream);
+int launch_sgd(float* master, const float* grad, void* copy_bf16, float lr, int64_t n, hipStream_t stream);
 int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t stream);
+int launch_im2col_t(const void* pixels, int pixel_dtype, void* dst, int R, int Rpad, const PatchGeom* g, int kpad,
+                    hipStream_t stream);
 int launch_cls_rows(const float* cls, const float* pos, void* x, int batch, int seq, int dim, int dtype,
                     hipStream_t stream);

@@ -122,3 +122,107 @@ def patch_embed(pixel_values: torch.Tensor, weight: torch.Tensor, bias: torch.Te
     _lib.check(_lib.load().vit_patch_embed_fwd(px.data_ptr(), wmat.data_ptr(), _ptr(bias), cls.data_ptr(),
                                                pos.data_ptr(), out.data_ptr(), b, c, h, patch_size, d, dt, _stream()))
     return out
+
+
+# --------------------------------------------------------------------------- training-step ops
+_EPI_GRAD = {"gelu": _lib.EPI_DGELU, "quick_gelu": _lib.EPI_DQUICK_GELU}
+
+
+def _bf16(t: torch.Tensor, name: str) -> torch.Tensor:
+    t = _dev(t, name)
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"{name}: the training kernels take bfloat16 activations, got {t.dtype}")
+    return t
+
+
+def linear_train(x, weight, bias, activation: str):
+    """fc1 of ViTMLP in a training forward: returns (act(x W^T + b), x W^T + b) -- the
+    pre-activation is what the backward multiplies with (modeling_vit.py:250-251)."""
+    x, w = _bf16(x, "x"), _bf16(weight, "weight")
+    b = _f32(bias, "bias")
+    m, k, n = x.numel() // x.shape[-1], x.shape[-1], w.shape[0]
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    pre = torch.empty_like(out)
+    _lib.check(_lib.load().vit_gemm_ex(x.data_ptr(), w.data_ptr(), _ptr(b), None, out.data_ptr(), pre.data_ptr(), m, n, k,
+                                       _EPI[activation], 0, _stream()))
+    return out, pre
+
+
+def linear_dgrad(dy, weight_t, pre_activation=None, activation: str | None = None):
+    """dX = dY W as an NT GEMM on the transposed weight ``weight_t`` = W^T ([in, out]); with
+    ``pre_activation`` the result is multiplied by act'(pre_activation) in the epilogue."""
+    dy, wt = _bf16(dy, "dy"), _bf16(weight_t, "weight_t")
+    m, k, n = dy.numel() // dy.shape[-1], dy.shape[-1], wt.shape[0]
+    out = torch.empty(*dy.shape[:-1], n, dtype=dy.dtype, device=dy.device)
+    epi, aux = _lib.EPI_BIAS, None
+    if pre_activation is not None:
+        epi, aux = _EPI_GRAD[activation], _bf16(pre_activation, "pre_activation").data_ptr()
+    _lib.check(_lib.load().vit_gemm_ex(dy.data_ptr(), wt.data_ptr(), None, aux, out.data_ptr(), None, m, n, k, epi, 0,
+                                       _stream()))
+    return out
+
+
+def transpose_pad(x2d, pad_to: int = 128, colsum: bool = False, skip_first_of: int = 0):
+    """[R, C] bf16 -> [C, Rpad] (zero padded), optionally with the fp32 column sums of the input."""
+    x2d = _bf16(x2d, "x")
+    rows_mem, c = x2d.shape
+    r = rows_mem if skip_first_of == 0 else rows_mem // (skip_first_of + 1) * skip_first_of
+    rpad = (r + pad_to - 1) // pad_to * pad_to
+    out = torch.empty(c, rpad, dtype=x2d.dtype, device=x2d.device)
+    cs = torch.zeros(c, dtype=torch.float32, device=x2d.device) if colsum else None
+    _lib.check(_lib.load().vit_transpose_pad(x2d.data_ptr(), out.data_ptr(), _ptr(cs), r, c, rpad, skip_first_of,
+                                             _stream()))
+    return (out, cs) if colsum else out
+
+
+def linear_wgrad(dy_t, x_t):
+    """dW [out, in] (fp32) = dY^T X from the transposed, zero-padded operands
+    dy_t = dY^T [out, Mpad], x_t = X^T [in, Mpad]."""
+    dy_t, x_t = _bf16(dy_t, "dy_t"), _bf16(x_t, "x_t")
+    if dy_t.shape[1] != x_t.shape[1]:
+        raise ValueError("linear_wgrad: operands disagree on the padded token count")
+    m, k, n = dy_t.shape[0], dy_t.shape[1], x_t.shape[0]
+    out = torch.empty(m, n, dtype=torch.float32, device=dy_t.device)
+    _lib.check(_lib.load().vit_gemm_ex(dy_t.data_ptr(), x_t.data_ptr(), None, None, out.data_ptr(), None, m, n, k,
+                                       _lib.EPI_BIAS, 1, _stream()))
+    return out
+
+
+def attention_train(qkv, num_heads: int):
+    """attention() that also returns the base-2 log-sum-exp [B, H, N] the backward needs."""
+    qkv = _bf16(qkv, "qkv")
+    b, n, d3 = qkv.shape
+    d = d3 // 3
+    out = torch.empty(b, n, d, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(b, num_heads, n, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().vit_attention_fwd_train(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), b, n, num_heads,
+                                                   d // num_heads, _stream()))
+    return out, lse
+
+
+def attention_backward(qkv, out, d_out, lse, num_heads: int):
+    """Gradient of attention() w.r.t. the packed qkv (eager_attention_forward, modeling_vit.py:164-189)."""
+    qkv, out, d_out = _bf16(qkv, "qkv"), _bf16(out, "out"), _bf16(d_out, "d_out")
+    b, n, d3 = qkv.shape
+    d = d3 // 3
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(b, num_heads, n, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().vit_attention_bwd(qkv.data_ptr(), out.data_ptr(), d_out.data_ptr(), lse.data_ptr(),
+                                             delta.data_ptr(), dqkv.data_ptr(), b, n, num_heads, d // num_heads,
+                                             _stream()))
+    return dqkv
+
+
+def layer_norm_backward(x, dy, weight, eps: float, d_residual=None):
+    """Returns (dx [+ d_residual], dgamma, dbeta) of nn.LayerNorm (modeling_vit.py:261-262)."""
+    x, dy = _bf16(x, "x"), _bf16(dy, "dy")
+    w = _f32(weight, "weight")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    dg = torch.zeros(d, dtype=torch.float32, device=x.device)
+    db = torch.zeros(d, dtype=torch.float32, device=x.device)
+    dres = None if d_residual is None else _bf16(d_residual, "d_residual").data_ptr()
+    _lib.check(_lib.load().vit_layernorm_bwd(x.data_ptr(), dy.data_ptr(), w.data_ptr(), dres, dx.data_ptr(),
+                                             dg.data_ptr(), db.data_ptr(), rows, d, float(eps), _stream()))
+    return dx, dg, db
