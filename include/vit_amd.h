@@ -173,6 +173,37 @@ int vit_layernorm_bwd(const void* x, const void* dy, const float* gamma, const v
  * group is skipped (token rows without CLS). C % 8 == 0, Rpad % 8 == 0. */
 int vit_transpose_pad(const void* src, void* dst, float* colsum, int R, int C, int Rpad, int group, void* stream);
 
+/* ---- whole training step (VIT_BF16 contexts). Buffers are caller-owned device memory:
+ *   stash      vit_train_stash_bytes(ctx, batch): activations the backward re-reads
+ *   workspace  vit_train_workspace_bytes(ctx, batch): scratch of forward_train and backward
+ *   grads      vit_grad_bytes(ctx): fp32 gradients of every parameter; vit_grad_slot gives the
+ *              byte offset / shape / row pitch of a tensor by its HF key name, and the tensors of
+ *              transformer layer l are one contiguous range (vit_grad_layer_range) = one
+ *              all-reduce bucket. ---- */
+size_t vit_train_stash_bytes(const vit_ctx* ctx, int batch);
+size_t vit_train_workspace_bytes(const vit_ctx* ctx, int batch);
+size_t vit_grad_bytes(const vit_ctx* ctx);
+int vit_grad_slot(vit_ctx* ctx, const char* name, size_t* offset_bytes, int64_t* rows, int64_t* cols, int64_t* pitch);
+int vit_grad_layer_range(vit_ctx* ctx, int layer, size_t* offset_bytes, size_t* bytes);
+/* fp32 master weights (from the loaded weights) + transposed weights for the data-gradient GEMMs.
+ * Allocates; call once after loading, not on the hot path. */
+int vit_train_init(vit_ctx* ctx, void* stream);
+int vit_train_refresh_transposes(vit_ctx* ctx, void* stream);
+/* vit_forward that also fills `stash` (ViTModel.forward MV:356-388 with every intermediate kept). */
+int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
+                      void* pooled_out, void* stash, size_t stash_bytes, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* Backward in stages, in order on one stream: stage 0 = head (needs d_hidden [batch, N, D] bf16, the
+ * gradient of last_hidden_state; CLIP contexts also take d_pooled [batch, D] or NULL; ViT contexts
+ * fold d_pooled into the CLS rows of d_hidden themselves), stages 1..L = layers L-1..0,
+ * stage L+1 = embeddings (needs the pixels). Stage 0 zeroes `grads`. After stage s the gradients
+ * written by that stage are final, so the caller may all-reduce them while later stages run. */
+int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_dev, int pixel_dtype, int batch,
+                       const void* d_hidden, const void* d_pooled, const void* stash, void* grads, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* SGD: master -= lr * grads for every parameter, then refresh the compute copies. */
+int vit_sgd_step(vit_ctx* ctx, const void* grads, float lr, void* stream);
+
 /* Elementwise dtype conversion (plumbing for weight / pixel ingestion). */
 int vit_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, void* stream);
 

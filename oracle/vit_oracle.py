@@ -153,3 +153,9 @@ def quantize_state_dict_bf16(sd):
     """Round weights to bf16 and back: what the bf16 GPU path actually holds. Lets a test
     separate 'weights were rounded' from 'arithmetic is wrong'."""
     return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+def forward_autograd(pixel_values, sd, cfg):
+    """Same function as forward() with autograd enabled: torch.autograd of this definition is the
+    oracle of the training-step kernels (the reference has no backward of its own)."""
+    return forward.__wrapped__(pixel_values, sd, cfg)

@@ -73,3 +73,61 @@ def test_two_rank_gather_matches_single_process(global_batch):
         assert p.exitcode == 0
     results = dict(q.get(timeout=5) for _ in range(2))
     assert results == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------- DP training: bucketed all-reduce
+class _FakeCfg:
+    num_hidden_layers = 3
+
+
+class _FakeTrainer:
+    """Stands in for ViTTrainer on CPU: a gradient arena with 3 contiguous layer ranges between a
+    head and a tail region; backward() fills it with rank-dependent values stage by stage."""
+
+    def __init__(self, rank):
+        self.cfg = _FakeCfg()
+        self.device = torch.device("cpu")
+        self.grads = torch.zeros(10 + 3 * 7 + 5)
+        self.rank = rank
+        self.calls = []
+
+    def layer_grad_range(self, layer):
+        return self.grads[10 + 7 * layer: 10 + 7 * (layer + 1)]
+
+    def backward(self, d_hidden, d_pooled, on_stage):
+        L = self.cfg.num_hidden_layers
+        for s in range(L + 2):
+            if 1 <= s <= L:
+                self.layer_grad_range(L - s).fill_(float((self.rank + 1) * (L - s + 1)))
+            elif s == 0:
+                self.grads[31:].fill_(float(self.rank + 1) * 100)
+            else:
+                self.grads[:10].fill_(float(self.rank + 1) * 1000)
+            self.calls.append(s)
+            on_stage(s)
+
+
+def _dp_train_worker(rank, world, port):
+    import torch.distributed as dist
+    from vit_amd.trainer import DataParallelTrainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = _FakeTrainer(rank)
+        dp = DataParallelTrainer(t)
+        dp.backward()
+        mean = sum(r + 1 for r in range(world)) / world
+        assert t.calls == [0, 1, 2, 3, 4]
+        for layer in range(3):
+            assert torch.allclose(t.layer_grad_range(layer), torch.full((7,), mean * (layer + 1)))
+        assert torch.allclose(t.grads[31:], torch.full((5,), mean * 100))
+        assert torch.allclose(t.grads[:10], torch.full((10,), mean * 1000))
+        views = dp.non_layer_ranges()
+        assert [v.numel() for v in views] == [10, 5]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_trainer_reduces_every_gradient_once_world2():
+    import torch.multiprocessing as mp
+    mp.spawn(_dp_train_worker, args=(2, 29617), nprocs=2, join=True)

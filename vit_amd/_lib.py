@@ -61,6 +61,19 @@ SIGNATURES = {
     "vit_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_float, c_void_p]),
     "vit_transpose_pad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vit_train_stash_bytes": (c_size_t, [c_void_p, c_int]),
+    "vit_train_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "vit_grad_bytes": (c_size_t, [c_void_p]),
+    "vit_grad_slot": (c_int, [c_void_p, c_char_p, POINTER(c_size_t), POINTER(c_int64), POINTER(c_int64),
+                              POINTER(c_int64)]),
+    "vit_grad_layer_range": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "vit_train_init": (c_int, [c_void_p, c_void_p]),
+    "vit_train_refresh_transposes": (c_int, [c_void_p, c_void_p]),
+    "vit_forward_train": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                  c_size_t, c_void_p]),
+    "vit_backward_stage": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_size_t, c_void_p]),
+    "vit_sgd_step": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
 }
 
 _lib = None

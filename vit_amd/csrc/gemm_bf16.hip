@@ -337,8 +337,10 @@ int launch_gemm_bf16(const void* A, const void* W, const float* bias, const void
                 "gemm: epilogue %d needs the residual / pre-activation operand", epi);
     // big Linear layers go to the persistent deep-pipelined kernel (gemm_bf16_8p.hip); tiny
     // problems (less than one 256x256 tile of work per 4 CUs) and K tails stay here
-    if (patch == nullptr && gemm_bf16_8p_eligible(M, N, K) && (long)M * N >= 64L * 256 * 256)
+    const int splits = (ext && ext->split_k > 1) ? ext->split_k : 1;
+    if (patch == nullptr && gemm_bf16_8p_eligible(M, N, K) && (long)M * N * splits >= 64L * 256 * 256)
         return launch_gemm_bf16_8p(A, W, bias, res, C, M, N, K, epi, ext, stream);
+    VIT_REQUIRE(splits == 1, "gemm: split-K requested for a shape the persistent kernel does not take");
     return launch_gemm_bf16_generic(A, W, bias, res, C, M, N, K, epi, patch, pos, stream, ext);
 }
 

@@ -74,9 +74,11 @@ struct PParams {
     const bf16_t* res;
     bf16_t* C;       // bf16 output (OUTM 0, 2) or, reinterpreted, the fp32 output (OUTM 1)
     bf16_t* Cpre;    // OUTM 2: second output, the pre-activation A W^T + bias (training forward)
-    int M, N, K;
+    int M, N, K;     // K = reduction length of ONE split
+    int lda;         // row pitch (elements) of A and W: K * splits
     int NT;      // tiles along N
-    int T;       // total tiles
+    int TMN;     // output tiles per split = ceil(M/256) * NT
+    int T;       // total work items = TMN * splits; split s writes the fp32 slab C + s*M*N (OUTM 1)
     int dbg;     // lab only (G8_LAB): bit0 = timing-only run without output stores
 };
 
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     unsigned a_of[2][2], w_of[2][2];          // per-lane byte offsets from the tile's first A / W row
     __amdgpu_buffer_rsrc_t Ar, Wr;            // wave-uniform buffer resources based at those rows
     auto set_tile = [&](int tile_idx) {   // staging offsets / bases for a tile
-        const int mt = tile_idx / P.NT, nt = tile_idx - mt * P.NT;
+        const int sp = tile_idx / P.TMN, t2 = tile_idx - sp * P.TMN;
+        const int mt = t2 / P.NT, nt = t2 - mt * P.NT;
         const int m0 = mt * BM, n0 = nt * BN;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -118,18 +121,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                 const int sw = (r >> 1) & 7;
                 int ar = h * 128 + r;
                 if (m0 + ar > P.M - 1) ar = P.M - 1 - m0;
-                a_of[h][j] = ((unsigned)ar * (unsigned)P.K + (unsigned)((p ^ sw) << 3)) * 2u;
+                a_of[h][j] = ((unsigned)ar * (unsigned)P.lda + (unsigned)((p ^ sw) << 3)) * 2u;
                 const int rr = r & 31;
                 // B half h, LDS row (wc*32 + ni*16 + c) holds tile column wc*64 + 4c + (2h + ni): the four
                 // 16-column MFMA fragments of a wave interleave to 4 consecutive columns per lane
                 int wrow = (r >> 5) * 64 + (rr & 15) * 4 + h * 2 + (rr >> 4);
                 if (n0 + wrow > P.N - 1) wrow = P.N - 1 - n0;
-                w_of[h][j] = ((unsigned)wrow * (unsigned)P.K + (unsigned)((p ^ sw) << 3)) * 2u;
+                w_of[h][j] = ((unsigned)wrow * (unsigned)P.lda + (unsigned)((p ^ sw) << 3)) * 2u;
             }
         // num_records spans the (clamped) 256 rows of the tile; offsets never exceed it
-        const unsigned span = (unsigned)BM * (unsigned)P.K * 2u;
-        Ar = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * P.K), 0, span, 0x00020000);
-        Wr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * P.K), 0, span, 0x00020000);
+        const unsigned span = (unsigned)BM * (unsigned)P.lda * 2u;
+        const size_t koff = (size_t)sp * P.K;  // this split's first k
+        Ar = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * P.lda + koff), 0, span, 0x00020000);
+        Wr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * P.lda + koff), 0, span, 0x00020000);
     };
     unsigned char* const dma_base = smem + wave * 1024;
     auto stage_a = [&](int h, int buf, int kt) {
@@ -265,7 +269,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             // resources based at the tile's first row: rows >= M fall outside num_records and are
             // dropped by the hardware range check; lanes whose columns are >= N get an offset that
             // is always out of range. No branches.
-            const int mt = cur_tile / P.NT, nt = cur_tile - mt * P.NT;
+            const int sp = cur_tile / P.TMN, t2 = cur_tile - sp * P.TMN;
+            const int mt = t2 / P.NT, nt = t2 - mt * P.NT;
             const int m0 = mt * BM, n0 = nt * BN;
             const int nb = n0 + wc * 64 + 4 * i;
             const bool col_ok = nb < P.N;  // N % 8 == 0: 4 columns all in or all out
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             constexpr unsigned OES = (OUTM == 1) ? 4u : 2u;  // output element size
             const unsigned span = (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * 2u;
             const __amdgpu_buffer_rsrc_t Cr = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)((char*)P.C + (size_t)m0 * P.N * OES), 0, (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * OES,
+                (void*)((char*)P.C + ((size_t)sp * P.M + m0) * P.N * OES), 0, (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * OES,
                 0x00020000);
             __amdgpu_buffer_rsrc_t Rr = Cr, Pr = Cr;
             if constexpr (USES_RES)
@@ -363,9 +368,11 @@ int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
 
 }  // namespace g8
 
+int launch_reduce_slabs(const float* slabs, float* out, int splits, int64_t n, hipStream_t stream);
+
 // true when the 8-phase kernel takes this problem
 bool gemm_bf16_8p_eligible(int M, int N, int K) {
-    return K % 128 == 0 && K >= 256 && N % 8 == 0 && M >= 1 && (size_t)256 * K * 2 < ((size_t)1 << 31);
+    return K % 128 == 0 && K >= 256 && N % 8 == 0 && M >= 1 && (size_t)256 * K * 2 < ((size_t)1 << 31);  // K here is the full row pitch
 }
 
 #ifdef G8_LAB
@@ -383,9 +390,14 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
     g8::PParams P{};
     P.A = (const bf16_t*)A; P.W = (const bf16_t*)W; P.bias = bias; P.res = (const bf16_t*)res; P.C = (bf16_t*)C;
     P.Cpre = ext ? (bf16_t*)ext->c_pre : nullptr;
-    P.M = M; P.N = N; P.K = K;
+    const int splits = (ext && ext->split_k > 1) ? ext->split_k : 1;
+    VIT_REQUIRE(K % (128 * splits) == 0 && K / splits >= 256, "gemm8p: K=%d not divisible into %d splits of whole K-tile pairs", K, splits);
+    VIT_REQUIRE(splits == 1 || (ext->out_f32 && ext->slabs != nullptr), "gemm8p: split-K needs fp32 output and a slab workspace");
+    P.M = M; P.N = N; P.K = K / splits; P.lda = K;
     P.NT = ceil_div(N, g8::BN);
-    P.T = ceil_div(M, g8::BM) * P.NT;
+    P.TMN = ceil_div(M, g8::BM) * P.NT;
+    P.T = P.TMN * splits;
+    if (splits > 1) P.C = (bf16_t*)ext->slabs;
 #ifdef G8_LAB
     P.dbg = g8_dbg;
 #endif
@@ -394,7 +406,11 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
     VIT_REQUIRE(!(f32out && (epi != VIT_EPI_BIAS || pre)), "gemm8p: fp32 output only with the plain epilogue");
     VIT_REQUIRE(!pre || epi == VIT_EPI_GELU || epi == VIT_EPI_QUICK_GELU, "gemm8p: pre-activation output needs an activation epilogue");
     VIT_REQUIRE((size_t)256 * N * (f32out ? 4 : 2) < ((size_t)1 << 31), "gemm8p: N too large");
-    if (f32out) return g8::launch_persist<VIT_EPI_BIAS, 1>(P, ncu, stream);
+    if (f32out) {
+        int rc = g8::launch_persist<VIT_EPI_BIAS, 1>(P, ncu, stream);
+        if (rc != VIT_OK || splits == 1) return rc;
+        return launch_reduce_slabs((const float*)ext->slabs, (float*)C, splits, (int64_t)M * N, stream);
+    }
     switch (epi) {
         case VIT_EPI_BIAS: return g8::launch_persist<VIT_EPI_BIAS, 0>(P, ncu, stream);
         case VIT_EPI_GELU: return pre ? g8::launch_persist<VIT_EPI_GELU, 2>(P, ncu, stream) : g8::launch_persist<VIT_EPI_GELU, 0>(P, ncu, stream);

@@ -234,7 +234,28 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ master, co
     }
 }
 
+// out[i] = sum_s slabs[s][i] in a fixed order (split-K weight gradients)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                           int splits, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;  // n % 4 == 0
+    f32x4 a = *(const f32x4*)(slabs + i);
+    for (int s = 1; s < splits; ++s) {
+        const f32x4 b = *(const f32x4*)(slabs + (size_t)s * n + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += b[e];
+    }
+    *(f32x4*)(out + i) = a;
+}
+
 }  // namespace
+
+int launch_reduce_slabs(const float* slabs, float* out, int splits, int64_t n, hipStream_t stream) {
+    VIT_REQUIRE(n % 4 == 0, "reduce_slabs: n %% 4 != 0");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, out, splits, n);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
 
 int launch_transpose_pad(const void* src, void* dst, float* colsum, int R, int C, int Rpad, int group,
                          hipStream_t stream) {

@@ -2,7 +2,7 @@
 // encoder forward (ViTModel.forward modeling_vit.py:356-388, CLIPVisionModel.forward
 // modeling_clip.py:641-656) as a fixed sequence of kernel launches on the caller's stream,
 // and thin argument-checking wrappers around the individual kernels.
-#include "vit_common.h"
+#include "vit_ctx.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -18,6 +18,8 @@ int launch_gemm_f32(const void* A, const void* W, const float* bias, const void*
                     int epi, const PatchGeom* patch, const float* pos, hipStream_t stream);
 int launch_convert_2d(const void* src, int sdt, void* dst, int ddt, int64_t rows, int64_t cols, int64_t dst_pitch,
                       hipStream_t stream);
+
+void vit_train_free(vit_ctx* ctx);  // vit_train.hip
 
 // ---------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -41,52 +43,18 @@ int launch_gemm(const void* A, const void* W, const float* bias, const void* res
     return vit_set_error(VIT_E_INVALID, "gemm: bad dtype %d", dtype);
 }
 
-// ---------------------------------------------------------------- context
-namespace {
-
-struct Slot {
-    size_t offset;      // bytes into the arena
-    int64_t rows, cols; // source shape as a matrix (vectors: rows = 1)
-    int64_t pitch;      // destination row pitch in elements
-    int dtype;          // storage dtype in the arena
-    bool loaded;
-};
-
-struct LayerW {
-    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
-    void *wqkv, *wo, *w1, *w2;
-};
-
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline size_t esize(int dt) { return dt == VIT_F32 ? 4 : 2; }
-
-}  // namespace
-
-struct vit_ctx {
-    vit_config cfg;
-    int device;
-    int N, dh, kreal, kpad;
-    unsigned char* arena;
-    size_t arena_bytes;
-    std::map<std::string, Slot> slots;
-    std::vector<std::string> optional;  // names that may legitimately stay unloaded (none today)
-    std::string missing_name;
-    int n_missing;
-    // resolved pointers
-    void* patch_w;
-    float *patch_b, *cls, *pos, *pre_g, *pre_b, *fin_g, *fin_b;
-    std::vector<LayerW> layers;
-};
-
 namespace {
 
 struct ArenaBuilder {
     size_t cur = 0;
+    size_t gcur = 0;  // fp32 gradient / master arena, in floats (rows * pitch per tensor, 64-float aligned)
     std::map<std::string, Slot>* slots;
-    size_t add(const std::string& name, int64_t rows, int64_t cols, int64_t pitch, int dtype) {
+    size_t add(const std::string& name, int64_t rows, int64_t cols, int64_t pitch, int dtype, size_t* goff = nullptr) {
         const size_t off = cur;
-        (*slots)[name] = Slot{off, rows, cols, pitch, dtype, false};
+        (*slots)[name] = Slot{off, rows, cols, pitch, dtype, false, gcur};
+        if (goff) *goff = gcur;
         cur = align256(cur + (size_t)rows * pitch * esize(dtype));
+        gcur = (gcur + (size_t)rows * pitch + 63) & ~(size_t)63;
         return off;
     }
     size_t raw(size_t bytes) {  // unnamed zero-initialised region
@@ -139,20 +107,22 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
     ab.slots = &ctx->slots;
     struct LayerOff { size_t ln1g, ln1b, ln2g, ln2b, bqkv, bo, b1, b2, wqkv, wo, w1, w2; };
     std::vector<LayerOff> lo(L);
+    ctx->glayers.resize(L);
+    ctx->g_pre_g = ctx->g_pre_b = ctx->g_patch_b = 0;
     size_t o_patch_w, o_patch_b, o_cls, o_pos, o_pre_g = 0, o_pre_b = 0, o_fin_g, o_fin_b;
 
     if (!clip) {
-        o_cls = ab.add("embeddings.cls_token", 1, D, D, VIT_F32);
-        o_pos = ab.add("embeddings.position_embeddings", 1, (int64_t)ctx->N * D, (int64_t)ctx->N * D, VIT_F32);
-        o_patch_w = ab.add("embeddings.patch_embeddings.projection.weight", D, ctx->kreal, ctx->kpad, T);
-        o_patch_b = ab.add("embeddings.patch_embeddings.projection.bias", 1, D, D, VIT_F32);
+        o_cls = ab.add("embeddings.cls_token", 1, D, D, VIT_F32, &ctx->g_cls);
+        o_pos = ab.add("embeddings.position_embeddings", 1, (int64_t)ctx->N * D, (int64_t)ctx->N * D, VIT_F32, &ctx->g_pos);
+        o_patch_w = ab.add("embeddings.patch_embeddings.projection.weight", D, ctx->kreal, ctx->kpad, T, &ctx->g_patch_w);
+        o_patch_b = ab.add("embeddings.patch_embeddings.projection.bias", 1, D, D, VIT_F32, &ctx->g_patch_b);
     } else {
-        o_cls = ab.add("embeddings.class_embedding", 1, D, D, VIT_F32);
-        o_pos = ab.add("embeddings.position_embedding.weight", 1, (int64_t)ctx->N * D, (int64_t)ctx->N * D, VIT_F32);
-        o_patch_w = ab.add("embeddings.patch_embedding.weight", D, ctx->kreal, ctx->kpad, T);
+        o_cls = ab.add("embeddings.class_embedding", 1, D, D, VIT_F32, &ctx->g_cls);
+        o_pos = ab.add("embeddings.position_embedding.weight", 1, (int64_t)ctx->N * D, (int64_t)ctx->N * D, VIT_F32, &ctx->g_pos);
+        o_patch_w = ab.add("embeddings.patch_embedding.weight", D, ctx->kreal, ctx->kpad, T, &ctx->g_patch_w);
         o_patch_b = ab.raw((size_t)D * 4);  // Conv2d(bias=False), modeling_clip.py:148-154
-        o_pre_g = ab.add("pre_layrnorm.weight", 1, D, D, VIT_F32);
-        o_pre_b = ab.add("pre_layrnorm.bias", 1, D, D, VIT_F32);
+        o_pre_g = ab.add("pre_layrnorm.weight", 1, D, D, VIT_F32, &ctx->g_pre_g);
+        o_pre_b = ab.add("pre_layrnorm.bias", 1, D, D, VIT_F32, &ctx->g_pre_b);
     }
     for (int l = 0; l < L; ++l) {
         char p[96];
@@ -167,39 +137,48 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
             q = "self_attn.q_proj"; k = "self_attn.k_proj"; v = "self_attn.v_proj"; o = "self_attn.out_proj";
         }
         const std::string pre(p);
-        lo[l].ln1g = ab.add(pre + ln1 + ".weight", 1, D, D, VIT_F32);
-        lo[l].ln1b = ab.add(pre + ln1 + ".bias", 1, D, D, VIT_F32);
-        lo[l].ln2g = ab.add(pre + ln2 + ".weight", 1, D, D, VIT_F32);
-        lo[l].ln2b = ab.add(pre + ln2 + ".bias", 1, D, D, VIT_F32);
+        LayerG& G = ctx->glayers[l];
+        G.begin = ab.gcur;
+        lo[l].ln1g = ab.add(pre + ln1 + ".weight", 1, D, D, VIT_F32, &G.ln1_g);
+        lo[l].ln1b = ab.add(pre + ln1 + ".bias", 1, D, D, VIT_F32, &G.ln1_b);
+        lo[l].ln2g = ab.add(pre + ln2 + ".weight", 1, D, D, VIT_F32, &G.ln2_g);
+        lo[l].ln2b = ab.add(pre + ln2 + ".bias", 1, D, D, VIT_F32, &G.ln2_b);
         // packed [3D, D] QKV: three slots into one matrix / one bias vector
         lo[l].wqkv = ab.cur;
         const bool has_qkv_bias = clip || c.qkv_bias;
         const char* names[3] = {q, k, v};
         for (int j = 0; j < 3; ++j) {
             (*ab.slots)[pre + names[j] + ".weight"] =
-                Slot{lo[l].wqkv + (size_t)j * D * D * esize(T), D, D, D, T, false};
+                Slot{lo[l].wqkv + (size_t)j * D * D * esize(T), D, D, D, T, false, ab.gcur + (size_t)j * D * D};
         }
         ab.cur = align256(ab.cur + (size_t)3 * D * D * esize(T));
+        G.wqkv = ab.gcur;
+        ab.gcur = (ab.gcur + (size_t)3 * D * D + 63) & ~(size_t)63;
+        G.bqkv = ab.gcur;
         lo[l].bqkv = ab.cur;
         for (int j = 0; j < 3; ++j)
             if (has_qkv_bias)
-                (*ab.slots)[pre + names[j] + ".bias"] = Slot{lo[l].bqkv + (size_t)j * D * 4, 1, D, D, VIT_F32, false};
+                (*ab.slots)[pre + names[j] + ".bias"] = Slot{lo[l].bqkv + (size_t)j * D * 4, 1, D, D, VIT_F32, false, ab.gcur + (size_t)j * D};
         ab.cur = align256(ab.cur + (size_t)3 * D * 4);
-        lo[l].wo = ab.add(pre + o + ".weight", D, D, D, T);
-        lo[l].bo = ab.add(pre + o + ".bias", 1, D, D, VIT_F32);
-        lo[l].w1 = ab.add(pre + "mlp.fc1.weight", F, D, D, T);
-        lo[l].b1 = ab.add(pre + "mlp.fc1.bias", 1, F, F, VIT_F32);
-        lo[l].w2 = ab.add(pre + "mlp.fc2.weight", D, F, F, T);
-        lo[l].b2 = ab.add(pre + "mlp.fc2.bias", 1, D, D, VIT_F32);
+        ab.gcur = (ab.gcur + (size_t)3 * D + 63) & ~(size_t)63;
+        lo[l].wo = ab.add(pre + o + ".weight", D, D, D, T, &G.wo);
+        lo[l].bo = ab.add(pre + o + ".bias", 1, D, D, VIT_F32, &G.bo);
+        lo[l].w1 = ab.add(pre + "mlp.fc1.weight", F, D, D, T, &G.w1);
+        lo[l].b1 = ab.add(pre + "mlp.fc1.bias", 1, F, F, VIT_F32, &G.b1);
+        lo[l].w2 = ab.add(pre + "mlp.fc2.weight", D, F, F, T, &G.w2);
+        lo[l].b2 = ab.add(pre + "mlp.fc2.bias", 1, D, D, VIT_F32, &G.b2);
+        G.end = ab.gcur;
     }
     if (!clip) {
-        o_fin_g = ab.add("layernorm.weight", 1, D, D, VIT_F32);
-        o_fin_b = ab.add("layernorm.bias", 1, D, D, VIT_F32);
+        o_fin_g = ab.add("layernorm.weight", 1, D, D, VIT_F32, &ctx->g_fin_g);
+        o_fin_b = ab.add("layernorm.bias", 1, D, D, VIT_F32, &ctx->g_fin_b);
     } else {
-        o_fin_g = ab.add("post_layernorm.weight", 1, D, D, VIT_F32);
-        o_fin_b = ab.add("post_layernorm.bias", 1, D, D, VIT_F32);
+        o_fin_g = ab.add("post_layernorm.weight", 1, D, D, VIT_F32, &ctx->g_fin_g);
+        o_fin_b = ab.add("post_layernorm.bias", 1, D, D, VIT_F32, &ctx->g_fin_b);
     }
     ctx->arena_bytes = ab.cur;
+    ctx->g_total = ab.gcur;
+    ctx->train = nullptr;
     hipError_t e = hipMalloc((void**)&ctx->arena, ctx->arena_bytes);
     if (e != hipSuccess) {
         delete ctx;
@@ -237,6 +216,7 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
 
 extern "C" int vit_destroy(vit_ctx* ctx) {
     if (!ctx) return VIT_OK;
+    vit_train_free(ctx);
     if (ctx->arena) (void)hipFree(ctx->arena);
     delete ctx;
     return VIT_OK;
@@ -424,7 +404,7 @@ extern "C" int vit_gemm_ex(const void* A, const void* W, const float* bias, cons
                            void* C_pre, int M, int N, int K, int epilogue, int out_f32, void* stream) {
     VIT_REQUIRE(A && W && C, "vit_gemm_ex: null argument");
     VIT_REQUIRE(epilogue >= VIT_EPI_BIAS && epilogue <= VIT_EPI_DQUICK_GELU, "vit_gemm_ex: bad epilogue %d", epilogue);
-    GemmExt ext{C_pre, out_f32};
+    GemmExt ext{C_pre, out_f32, 1, nullptr};
     return launch_gemm(A, W, bias, residual_or_aux, C, M, N, K, epilogue, VIT_BF16, nullptr, nullptr, (hipStream_t)stream,
                        &ext);
 }

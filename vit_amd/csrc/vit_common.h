@@ -113,6 +113,9 @@ struct PatchGeom {  // im2col-free A operand of the patch-embedding GEMM
 struct GemmExt {
     void* c_pre;   // activation epilogues: also store the pre-activation A W^T + bias here (bf16 [M,N])
     int out_f32;   // plain epilogue: C is fp32 [M,N] (weight gradients)
+    int split_k;   // > 1 (fp32 output, persistent kernel only): K is cut into split_k ranges, each
+                   // written to its own fp32 slab, then summed in a fixed order (reproducible)
+    float* slabs;  // split_k * M * N floats
 };
 
 // C = epi(A W^T + bias (+res)); `patch` non-null => A is the pixel tensor, rows are patches,

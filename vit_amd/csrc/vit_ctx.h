@@ -1,0 +1,53 @@
+// Context of libvit_amd.so shared by vit_capi.hip (inference) and vit_train.hip (training step).
+#pragma once
+#include "vit_common.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+struct Slot {
+    size_t offset;      // bytes into the weight arena
+    int64_t rows, cols; // source shape as a matrix (vectors: rows = 1)
+    int64_t pitch;      // destination row pitch in elements
+    int dtype;          // storage dtype in the arena
+    bool loaded;
+    size_t goff;        // element offset of the same tensor in the fp32 gradient / master arenas (same pitch)
+};
+
+struct LayerW {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
+    void *wqkv, *wo, *w1, *w2;
+};
+
+// fp32-arena element offsets of one layer's tensors (gradients and master weights share them)
+struct LayerG {
+    size_t ln1_g, ln1_b, ln2_g, ln2_b, bqkv, bo, b1, b2, wqkv, wo, w1, w2;
+    size_t begin, end;  // [begin, end): the layer's contiguous range (one all-reduce bucket)
+};
+
+struct TrainState;  // vit_train.hip
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline size_t esize(int dt) { return dt == VIT_F32 ? 4 : 2; }
+
+struct vit_ctx {
+    vit_config cfg;
+    int device;
+    int N, dh, kreal, kpad;
+    unsigned char* arena;
+    size_t arena_bytes;
+    std::map<std::string, Slot> slots;
+    std::vector<std::string> optional;  // names that may legitimately stay unloaded (none today)
+    std::string missing_name;
+    int n_missing;
+    // resolved pointers
+    void* patch_w;
+    float *patch_b, *cls, *pos, *pre_g, *pre_b, *fin_g, *fin_b;
+    std::vector<LayerW> layers;
+    // fp32 gradient-arena layout
+    size_t g_total;  // floats
+    size_t g_patch_w, g_patch_b, g_cls, g_pos, g_pre_g, g_pre_b, g_fin_g, g_fin_b;
+    std::vector<LayerG> glayers;
+    TrainState* train;
+};
