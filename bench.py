@@ -99,6 +99,20 @@ def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
     return out
 
 
+def pmc_traffic_bytes(kernel_key: str):
+    """Bytes beyond L2 per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01b_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same script, with
+    the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced
+    read). Counters cannot be read from inside the process, so this is the recorded figure for
+    the same workload, or None when the file or the kernel is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01b_traffic.json")) as f:
+            rec = json.load(f)["per_launch_kb"].get(kernel_key)
+        return None if rec is None else (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg: ViTConfig, budget_s: float = 12.0):
     """The CPU oracle on this host: fp32, batch 8 (BASELINE.json configs[0])."""
     from oracle import vit_oracle
@@ -116,6 +130,62 @@ def cpu_baseline(cfg: ViTConfig, budget_s: float = 12.0):
             "sample": f"{n} forwards of batch 8, ViT-B/16 224^2 fp32, oracle/vit_oracle.py (plain torch CPU)"}
 
 
+def train_main(args, cfg, enc, px, rank, world, dev, dist):
+    """BASELINE.json configs[4]: forward + backward + SGD on 256 images per GPU; for N > 1 the
+    gradients are all-reduced over RCCL, one bucket per transformer layer, overlapped with the
+    backward of the next layer. Synthetic regression target on the CLS embedding."""
+    from vit_amd.trainer import DataParallelTrainer, ViTTrainer
+    tr = ViTTrainer(enc)
+    dp = DataParallelTrainer(tr) if world > 1 else None
+    target = synth.normal((LOCAL_BATCH, cfg.hidden_size), 7 + rank, "target", device=dev)
+
+    def step():
+        out = tr.forward(px)
+        d = (out.pooler_output.float() - target).mul_(1.0 / LOCAL_BATCH).to(torch.bfloat16)
+        if dp is not None:
+            dp.backward(None, d)
+        else:
+            tr.backward(None, d)
+        tr.sgd_step(1e-3)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(out.pooler_output).all(), "non-finite embeddings"
+    if rank == 0:
+        value = world * LOCAL_BATCH * args.steps / elapsed
+        flops = value * 3 * cfg.flops_per_image()  # backward = 2x forward (dgrad + wgrad)
+        print(json.dumps({
+            "metric": "images/sec ViT-B/16 224^2 bf16 training step (forward + backward + SGD)", "value": value,
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ViT-B/16 224^2 bf16 training step, batch 256 per MI355X (BASELINE.json configs[4])",
+                       "global_batch": world * LOCAL_BATCH, "seq_len": cfg.seq_len,
+                       "parallelism": f"dp{world}" + (" + RCCL gradient all-reduce per layer" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "achieved": flops / 1e12, "peak": world * MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": flops / (world * MFMA_BF16_PEAK), "traffic": None,
+                         "kernel": "whole step, 3 x forward FLOPs"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +193,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--workload", choices=("forward", "train"), default="forward",
+                    help="forward = the headline metric (BASELINE.json configs[1]); train = fwd+bwd+SGD step with the "
+                         "gradient all-reduce (configs[4]), reported as images/sec of the training step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,6 +214,8 @@ def main():
     enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=dev)
     enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0, device=dev))
     px = synth.synthetic_images(cfg, LOCAL_BATCH, seed=1 + rank, device=dev).to(torch.bfloat16)
+    if args.workload == "train":
+        return train_main(args, cfg, enc, px, rank, world, dev, dist)
     gathered = torch.empty(world * LOCAL_BATCH, cfg.hidden_size, dtype=torch.bfloat16, device=dev) if world > 1 else None
 
     def step():
@@ -188,8 +263,8 @@ def main():
                       key=lambda k: ks[k]["us_per_launch"] * ks[k]["launches_per_forward"])
             r = ks[dom]
             line["roofline"] = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
-                                "frac": r["frac"], "traffic": None, "kernel": "gemm_bf16_kernel (" + dom + ")",
-                                "us_per_launch": r["us_per_launch"]}
+                                "frac": r["frac"], "traffic": pmc_traffic_bytes(dom),
+                                "kernel": "g8::gemm8p_persist_kernel (" + dom + ")", "us_per_launch": r["us_per_launch"]}
             line["kernels"] = ks
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)

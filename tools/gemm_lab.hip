@@ -21,6 +21,8 @@ int vit_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+int launch_reduce_slabs(const float*, float*, int, int64_t, hipStream_t) { return 0; }  // lab stub (split-K unused here)
+
 namespace lab {
 
 template <int WM_, int WN_, int NSLOTS, int EPI>
@@ -194,8 +196,8 @@ int main(int argc, char** argv) {
         std::vector<Var> vars;
         vars.push_back({"shipped", [&](bf16_t* C) { launch_gemm_bf16_generic(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, nullptr, st); }});
         vars.push_back({"ring<2,4,4>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<2, 4, 4, VIT_EPI_GELU>(Q, st) : lab::launch_ring<2, 4, 4, VIT_EPI_BIAS>(Q, st); }});
-        vars.push_back({"g8p", [&](bf16_t* C) { launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, st); }});
-        vars.push_back({"ns8p", [&](bf16_t* C) { g8_dbg = 1; launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, st); g8_dbg = 0; }});
+        vars.push_back({"g8p", [&](bf16_t* C) { launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); }});
+        vars.push_back({"ns8p", [&](bf16_t* C) { g8_dbg = 1; launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); g8_dbg = 0; }});
         vars.push_back({"ring<2,2,3>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<2, 2, 3, VIT_EPI_GELU>(Q, st) : lab::launch_ring<2, 2, 3, VIT_EPI_BIAS>(Q, st); }});
         vars.push_back({"ring<1,4,3>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<1, 4, 3, VIT_EPI_GELU>(Q, st) : lab::launch_ring<1, 4, 3, VIT_EPI_BIAS>(Q, st); }});
         if (*var_f) { std::vector<Var> keep; for (auto& v : vars) if (!strcmp(v.name, "shipped") || strstr(var_f, v.name)) keep.push_back(v); vars = keep; }
