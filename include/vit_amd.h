@@ -204,6 +204,51 @@ int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_dev, int pixe
 /* SGD: master -= lr * grads for every parameter, then refresh the compute copies. */
 int vit_sgd_step(vit_ctx* ctx, const void* grads, float lr, void* stream);
 
+/* ---- the steps directly before and after the encoder ---- */
+
+/* Heads on the pooled row. out[b, :] = act(W x_b + bias), x_b = x + b * x_row_stride (elements), so
+ * the CLS row of last_hidden_state [batch, N, D] is read in place with x_row_stride = N * D.
+ *   VIT_HEAD_TANH   + bias: ViTPooler.forward, pooled = tanh(dense(hidden[:, 0]))       (MV:289-301)
+ *   VIT_HEAD_LINEAR no bias: CLIPVisionModelWithProjection.visual_projection(pooled)    (MC:907, :950)
+ * x, weight [out_dim, in_dim], out [batch, out_dim] of `dtype`; bias fp32 or NULL; in_dim and
+ * x_row_stride multiples of 8 (bf16) / 4 (fp32). */
+#define VIT_HEAD_LINEAR 0
+#define VIT_HEAD_TANH 1
+int vit_head_fwd(const void* x, int64_t x_row_stride, const void* weight, const float* bias, void* out, int batch,
+                 int in_dim, int out_dim, int activation, int dtype, void* stream);
+
+/* Image preprocessing: decoded uint8 images [batch, in_height, in_width, channels] (HWC, all the same
+ * size) -> pixel_values [batch, channels, H, W] fp32 or bf16. This is what the remote model servers
+ * do with the file the reference sends them (Vlm_coder.py:24-26,:205,:381; vlm_cad.py:40,:171);
+ * the arithmetic follows transformers' PIL pipeline bit for bit: resize (Pillow ImagingResample,
+ * 8-bit fixed point, horizontal then vertical) -> center_crop (zero padding when the image is
+ * smaller) -> rescale -> normalize (image_processing_backends.py:619-653, image_transforms.py:89-126,
+ * :313-381, :384-442, :445-526). `resample` takes PIL's filter codes. */
+#define VIT_RESAMPLE_LANCZOS 1
+#define VIT_RESAMPLE_BILINEAR 2
+#define VIT_RESAMPLE_BICUBIC 3
+#define VIT_RESAMPLE_BOX 4
+#define VIT_RESAMPLE_HAMMING 5
+typedef struct vit_preproc vit_preproc;
+typedef struct vit_preproc_config {
+    int32_t in_height, in_width, channels; /* channels: 1 or 3 */
+    int32_t resize_height, resize_width;   /* 0, 0 = do_resize False */
+    int32_t crop_height, crop_width;       /* 0, 0 = do_center_crop False */
+    int32_t resample;                      /* VIT_RESAMPLE_* */
+    int32_t do_rescale, do_normalize;
+    double rescale_factor;                 /* 1/255 */
+    float image_mean[4], image_std[4];
+} vit_preproc_config;
+/* Builds the tap tables for one input geometry and uploads them (allocates; not on the hot path). */
+int vit_preproc_create(const vit_preproc_config* cfg, vit_preproc** out);
+int vit_preproc_destroy(vit_preproc* plan);
+int vit_preproc_output_size(const vit_preproc* plan, int* height, int* width);
+size_t vit_preproc_workspace_bytes(const vit_preproc* plan, int batch);
+/* Two launches on `stream`; `workspace` (16-byte aligned) holds the uint8 intermediate of the
+ * horizontal pass. Nothing is allocated. */
+int vit_preproc_run(vit_preproc* plan, const void* images_dev, int batch, void* pixel_values_out, int out_dtype,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* Elementwise dtype conversion (plumbing for weight / pixel ingestion). */
 int vit_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, void* stream);
 

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER, Structure
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER, Structure
 
 VIT_F32, VIT_BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_DQUICK_GELU = 0, 1, 2, 3, 4, 5
@@ -33,6 +33,15 @@ class vit_config(Structure):
                 ("num_channels", c_int32), ("hidden_act", c_int32), ("variant", c_int32), ("qkv_bias", c_int32),
                 ("dtype", c_int32), ("layer_norm_eps", c_float)]
 
+
+class vit_preproc_config(Structure):
+    _fields_ = [("in_height", c_int32), ("in_width", c_int32), ("channels", c_int32), ("resize_height", c_int32),
+                ("resize_width", c_int32), ("crop_height", c_int32), ("crop_width", c_int32), ("resample", c_int32),
+                ("do_rescale", c_int32), ("do_normalize", c_int32), ("rescale_factor", c_double),
+                ("image_mean", c_float * 4), ("image_std", c_float * 4)]
+
+
+HEAD_LINEAR, HEAD_TANH = 0, 1
 
 # name -> (restype, argtypes): every symbol include/vit_amd.h declares
 SIGNATURES = {
@@ -74,6 +83,13 @@ SIGNATURES = {
     "vit_backward_stage": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
     "vit_sgd_step": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
+    "vit_head_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                             c_void_p]),
+    "vit_preproc_create": (c_int, [POINTER(vit_preproc_config), POINTER(c_void_p)]),
+    "vit_preproc_destroy": (c_int, [c_void_p]),
+    "vit_preproc_output_size": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "vit_preproc_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "vit_preproc_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

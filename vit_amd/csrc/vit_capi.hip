@@ -394,6 +394,15 @@ extern "C" int vit_patch_embed_fwd(const void* pixels, const void* weight, const
                        VIT_EPI_BIAS, dtype, &pg, pos, (hipStream_t)stream);
 }
 
+int launch_head(const void* x, int64_t xs, const void* W, const float* bias, void* out, int batch, int K, int N, int act,
+                int dtype, hipStream_t stream);  // heads.hip
+
+extern "C" int vit_head_fwd(const void* x, int64_t x_row_stride, const void* weight, const float* bias, void* out,
+                            int batch, int in_dim, int out_dim, int activation, int dtype, void* stream) {
+    VIT_REQUIRE(x && weight && out, "vit_head_fwd: null argument");
+    return launch_head(x, x_row_stride, weight, bias, out, batch, in_dim, out_dim, activation, dtype, (hipStream_t)stream);
+}
+
 extern "C" int vit_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, void* stream) {
     VIT_REQUIRE(src && dst, "vit_convert: null argument");
     return launch_convert(src, src_dtype, dst, dst_dtype, numel, (hipStream_t)stream);

@@ -24,6 +24,7 @@ class EncoderOutput:
     """Same field names as transformers' BaseModelOutputWithPooling."""
     last_hidden_state: torch.Tensor
     pooler_output: torch.Tensor
+    image_embeds: Optional[torch.Tensor] = None  # CLIPVisionModelWithProjection output (projection_dim set)
 
     def __iter__(self):
         yield self.last_hidden_state
@@ -36,9 +37,23 @@ class ViTEncoder:
     >>> enc = ViTEncoder(ViTConfig(), dtype=torch.bfloat16, device="cuda:0")
     >>> enc.load_state_dict(hf_state_dict)      # HF key names
     >>> out = enc(pixel_values)                 # out.last_hidden_state [B,N,D], out.pooler_output [B,D]
+
+    Heads. ``add_pooling_layer=True`` (ViT) makes ``pooler_output`` =
+    tanh(dense(CLS)) as ``ViTModel(config, add_pooling_layer=True)`` does (modeling_vit.py:289-301;
+    keys ``pooler.dense.{weight,bias}``); ``projection_dim=P`` (CLIP) adds ``image_embeds`` =
+    visual_projection(pooler_output) as ``CLIPVisionModelWithProjection`` does (modeling_clip.py:907,
+    :950; key ``visual_projection.weight``). Both run ``vit_head_fwd`` on the pooled row.
     """
 
-    def __init__(self, config: ViTConfig, dtype: torch.dtype = torch.bfloat16, device="cuda"):
+    def __init__(self, config: ViTConfig, dtype: torch.dtype = torch.bfloat16, device="cuda",
+                 add_pooling_layer: bool = False, projection_dim: Optional[int] = None):
+        if add_pooling_layer and config.variant != "vit":
+            raise ValueError("add_pooling_layer is the ViTModel pooler; CLIP contexts use projection_dim")
+        if projection_dim is not None and config.variant != "clip":
+            raise ValueError("projection_dim is the CLIP visual_projection; ViT contexts use add_pooling_layer")
+        self.add_pooling_layer = add_pooling_layer
+        self.projection_dim = projection_dim
+        self._head: dict = {}
         self.config = config
         self.dtype = dtype
         self.device = torch.device(device)
@@ -74,6 +89,13 @@ class ViTEncoder:
                         name = name[len(prefix):]
                 if not torch.is_tensor(t) or not t.is_floating_point():
                     continue
+                if name in self._head_keys():
+                    want = self._head_keys()[name]
+                    if tuple(t.shape) != want:
+                        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {want}")
+                    # matrices in the compute dtype, bias fp32 (same rule as the arena)
+                    self._head[name] = t.to(self.device, torch.float32 if name.endswith(".bias") else self.dtype).contiguous()
+                    continue
                 if t.dtype not in (torch.float32, torch.bfloat16):
                     t = t.float()
                 src = t.to(self.device).contiguous()
@@ -90,6 +112,25 @@ class ViTEncoder:
             n = lib.vit_missing_weights(self._ctx, ctypes.byref(first))
             if n:
                 raise KeyError(f"{n} tensors missing from state_dict, e.g. {first.value.decode()!r}")
+            for k in self._head_keys():
+                if k not in self._head:
+                    raise KeyError(f"1 tensors missing from state_dict, e.g. {k!r}")
+
+    def _head_keys(self) -> dict:
+        d = self.config.hidden_size
+        if self.add_pooling_layer:
+            return {"pooler.dense.weight": (d, d), "pooler.dense.bias": (d,)}
+        if self.projection_dim is not None:
+            return {"visual_projection.weight": (self.projection_dim, d)}
+        return {}
+
+    def _head_fwd(self, x: torch.Tensor, weight: torch.Tensor, bias, activation: int) -> torch.Tensor:
+        out = torch.empty(x.shape[0], weight.shape[0], dtype=self.dtype, device=self.device)
+        _lib.check(_lib.load().vit_head_fwd(x.data_ptr(), x.stride(0), weight.data_ptr(),
+                                            bias.data_ptr() if bias is not None else None, out.data_ptr(), x.shape[0],
+                                            weight.shape[1], weight.shape[0], activation, dtype_code(self.dtype),
+                                            torch.cuda.current_stream().cuda_stream))
+        return out
 
     # ---- forward ----
     def workspace_bytes(self, batch: int) -> int:
@@ -116,7 +157,9 @@ class ViTEncoder:
             raise ValueError(f"Input image size ({h}*{w}) doesn't match model ({cfg.image_size}*{cfg.image_size}).")
         if b == 0:
             return EncoderOutput(torch.empty(0, cfg.seq_len, cfg.hidden_size, dtype=self.dtype, device=self.device),
-                                 torch.empty(0, cfg.hidden_size, dtype=self.dtype, device=self.device))
+                                 torch.empty(0, cfg.hidden_size, dtype=self.dtype, device=self.device),
+                                 None if self.projection_dim is None else
+                                 torch.empty(0, self.projection_dim, dtype=self.dtype, device=self.device))
         if pixel_values.dtype not in (torch.float32, torch.bfloat16):
             pixel_values = pixel_values.float()
         px = pixel_values.to(self.device).contiguous()
@@ -127,7 +170,14 @@ class ViTEncoder:
             _lib.check(_lib.load().vit_forward(self._ctx, px.data_ptr(), dtype_code(px.dtype), b, hidden.data_ptr(),
                                                pooled.data_ptr(), ws.data_ptr(), ws.numel(),
                                                torch.cuda.current_stream().cuda_stream))
-        return EncoderOutput(hidden, pooled)
+            embeds = None
+            if self.add_pooling_layer:
+                # ViTPooler reads the CLS row of the final-LayerNorm output in place (row stride N*D)
+                pooled = self._head_fwd(hidden[:, 0], self._head["pooler.dense.weight"],
+                                        self._head["pooler.dense.bias"], _lib.HEAD_TANH)
+            elif self.projection_dim is not None:
+                embeds = self._head_fwd(pooled, self._head["visual_projection.weight"], None, _lib.HEAD_LINEAR)
+        return EncoderOutput(hidden, pooled, embeds)
 
     __call__ = forward
 

@@ -126,3 +126,22 @@ def synthetic_state_dict(cfg: ViTConfig, seed: int = 0, device="cpu") -> dict:
 def synthetic_images(cfg: ViTConfig, batch: int, seed: int = 1, device="cpu") -> torch.Tensor:
     """pixel_values ~ N(0,1), fp32, [B, C, H, W]."""
     return normal((batch, cfg.num_channels, cfg.image_size, cfg.image_size), seed, "pixel_values", device=device)
+
+
+def synthetic_uint8_image(height: int, width: int, channels: int = 3, seed: int = 2, name: str = "image",
+                          device="cpu") -> torch.Tensor:
+    """Decoded-image stand-in, uint8 [H, W, C]: 8x8 blocks that are black, white or a flat random
+    colour (hard edges make bicubic / Lanczos overshoot, so the clip-to-uint8 paths are exercised)
+    with per-pixel noise on a quarter of the pixels. Pure integer hash of (seed, name, index)."""
+    key = _stream_key(seed, name)
+    y = torch.arange(height, dtype=torch.int64, device=device).view(-1, 1, 1)
+    x = torch.arange(width, dtype=torch.int64, device=device).view(1, -1, 1)
+    c = torch.arange(channels, dtype=torch.int64, device=device).view(1, 1, -1)
+    blk = _hash32(((y // 8) * 4099 + (x // 8)) * 7 + key)            # per block
+    blk_c = _hash32(blk + c * 0x9E37 + 1)                              # per block and channel
+    kind = blk % 4                                                     # 0 black, 1 white, 2/3 flat colour
+    base = torch.where(kind == 0, torch.zeros_like(blk_c), torch.where(kind == 1, torch.full_like(blk_c, 255),
+                                                                       blk_c & 255))
+    pix = _hash32(((y * width + x) * channels + c) ^ ((key * 0x85EBCA6B) & _M32))
+    noisy = (pix >> 8) % 4 == 0
+    return torch.where(noisy, pix & 255, base).to(torch.uint8)
