@@ -249,6 +249,19 @@ size_t vit_preproc_workspace_bytes(const vit_preproc* plan, int batch);
 int vit_preproc_run(vit_preproc* plan, const void* images_dev, int batch, void* pixel_values_out, int out_dtype,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Position-embedding interpolation for another input resolution:
+ * ViTEmbeddings.interpolate_pos_encoding (MV:89-127; CLIP MC:161-200): CLS row kept, the
+ * [src_grid, src_grid, dim] patch rows resized to [dst_grid_h, dst_grid_w, dim] with
+ * nn.functional.interpolate(mode="bicubic", align_corners=False). src [1 + src_grid^2, dim] and
+ * dst [1 + dst_grid_h * dst_grid_w, dim] are fp32 device tables. */
+int vit_pos_embed_interpolate(const float* src, float* dst, int dim, int src_grid, int dst_grid_h, int dst_grid_w,
+                              void* stream);
+/* A second context for inputs of image_size x image_size (a multiple of the patch size): all weights
+ * are device-to-device copies of `src`'s, the position table is interpolated -- what
+ * model(pixel_values, interpolate_pos_encoding=True) computes on every call (MV:147-148), done once.
+ * Allocates like vit_create (not on the hot path). Square resolutions only. */
+int vit_clone_resized(vit_ctx* src, int image_size, vit_ctx** out, void* stream);
+
 /* Elementwise dtype conversion (plumbing for weight / pixel ingestion). */
 int vit_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t numel, void* stream);
 

@@ -149,6 +149,28 @@ def forward(pixel_values, sd, cfg, trace=None):
     return x, pooled
 
 
+def interpolate_pos_encoding(pos, new_grid_h, new_grid_w):
+    """ViTEmbeddings.interpolate_pos_encoding (modeling_vit.py:89-127; CLIP modeling_clip.py:161-200)
+    on a [1 + g*g, D] table: CLS row kept, patch rows bicubic-resized (align_corners=False)."""
+    pos = pos.reshape(-1, pos.shape[-1]).float()
+    g = int(round((pos.shape[0] - 1) ** 0.5))
+    d = pos.shape[1]
+    patch = pos[1:].reshape(1, g, g, d).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, size=(new_grid_h, new_grid_w), mode="bicubic", align_corners=False)
+    return torch.cat([pos[:1], patch.permute(0, 2, 3, 1).reshape(-1, d)], dim=0)
+
+
+def resized_state_dict(sd, cfg, image_size):
+    """State dict + config of the same model at another (square) resolution."""
+    import dataclasses
+    key = "embeddings.position_embeddings" if cfg.variant == "vit" else "embeddings.position_embedding.weight"
+    g = image_size // cfg.patch_size
+    new = dict(sd)
+    p = interpolate_pos_encoding(sd[key], g, g)
+    new[key] = p.reshape(1, -1, p.shape[-1]) if cfg.variant == "vit" else p
+    return new, dataclasses.replace(cfg, image_size=image_size)
+
+
 def quantize_state_dict_bf16(sd):
     """Round weights to bf16 and back: what the bf16 GPU path actually holds. Lets a test
     separate 'weights were rounded' from 'arithmetic is wrong'."""

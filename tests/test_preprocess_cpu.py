@@ -114,3 +114,17 @@ def test_gpu_only_constructor():
         ImageProcessor(device="cpu")
     with pytest.raises(ValueError, match="resample"):
         ImageProcessor(resample=0, device="cpu")
+
+
+def test_pos_interp_oracle_matches_golden():
+    from oracle import vit_oracle
+    z = np.load(os.path.join(GOLDEN, "pos_interp_tiny.npz"), allow_pickle=False)
+    pos = synth.normal((1, 17, 64), 0, "pos", std=0.5)
+    for key in ("g6x6", "g2x2", "g5x9", "g1x1"):
+        gh, gw = (int(v) for v in key[1:].split("x"))
+        got = vit_oracle.interpolate_pos_encoding(pos, gh, gw).numpy()
+        assert np.abs(got - z[key]).max() <= 1e-6
+    p2 = synth.normal((5, 64), 0, "pos2", std=0.5)
+    assert np.abs(vit_oracle.interpolate_pos_encoding(p2, 3, 3).numpy() - z["clip_g3x3"]).max() <= 1e-6
+    # same grid: bicubic with align_corners=False at scale 1 is the identity
+    assert torch.allclose(vit_oracle.interpolate_pos_encoding(pos, 4, 4), pos[0], atol=1e-6)

@@ -85,6 +85,8 @@ SIGNATURES = {
     "vit_sgd_step": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
     "vit_head_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_void_p]),
+    "vit_pos_embed_interpolate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vit_clone_resized": (c_int, [c_void_p, c_int, POINTER(c_void_p), c_void_p]),
     "vit_preproc_create": (c_int, [POINTER(vit_preproc_config), POINTER(c_void_p)]),
     "vit_preproc_destroy": (c_int, [c_void_p]),
     "vit_preproc_output_size": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),

@@ -9,6 +9,7 @@ torch only owns the tensors, the workspace and the stream.
 from __future__ import annotations
 
 import ctypes
+import dataclasses
 from dataclasses import dataclass
 from typing import Mapping, Optional
 
@@ -143,11 +144,37 @@ class ViTEncoder:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward(self, pixel_values: torch.Tensor) -> EncoderOutput:
+    def with_image_size(self, image_size: int) -> "ViTEncoder":
+        """A second encoder for ``image_size`` x ``image_size`` inputs: same weights, position table
+        interpolated as ``interpolate_pos_encoding`` does (modeling_vit.py:89-127,
+        modeling_clip.py:161-200). Cached per size."""
+        if image_size == self.config.image_size:
+            return self
+        cache = self.__dict__.setdefault("_resized", {})
+        if image_size not in cache:
+            if image_size <= 0 or image_size % self.config.patch_size:
+                raise ValueError(f"image size {image_size} is not a multiple of the patch size {self.config.patch_size}")
+            new = object.__new__(ViTEncoder)
+            new.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_ctx", "_ws", "_resized", "config")})
+            new.config = dataclasses.replace(self.config, image_size=image_size)
+            new._ws = None
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().vit_clone_resized(self._ctx, image_size, ctypes.byref(handle),
+                                                         torch.cuda.current_stream().cuda_stream))
+            new._ctx = handle
+            cache[image_size] = new
+        return cache[image_size]
+
+    def forward(self, pixel_values: torch.Tensor, interpolate_pos_encoding: bool = False) -> EncoderOutput:
         cfg = self.config
         if pixel_values.dim() != 4:
             raise ValueError("pixel_values must be [batch, channels, height, width]")
         b, c, h, w = pixel_values.shape
+        if interpolate_pos_encoding and (h != cfg.image_size or w != cfg.image_size) and c == cfg.num_channels:
+            if h != w:
+                raise ValueError(f"interpolate_pos_encoding supports square inputs only (got {h}*{w})")
+            return self.with_image_size(h).forward(pixel_values)
         if c != cfg.num_channels:
             # same check as ViTPatchEmbeddings.forward (modeling_vit.py:63-68)
             raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
@@ -182,6 +209,8 @@ class ViTEncoder:
     __call__ = forward
 
     def close(self) -> None:
+        for e in self.__dict__.pop("_resized", {}).values():
+            e.close()
         if getattr(self, "_ctx", None) is not None and self._ctx:
             torch.cuda.synchronize(self.device)
             _lib.load().vit_destroy(self._ctx)
