@@ -15,7 +15,7 @@
 //    of ((v * rescale_factor) - mean) / std evaluated with numpy's operation order, and uploads them.
 //  * pass H: one workgroup stages ROWS_H input rows in LDS with dword loads and produces the
 //    resized-width rows (uint8, row pitch padded to 16 B) -- only the rows / columns the crop needs.
-//  * pass V: one workgroup per output row; a lane owns 4 adjacent pixels x C channels (dword
+//  * pass V: one workgroup per ROWS_V output rows; a lane owns 4 adjacent pixels x C channels (dword
 //    loads of the intermediate), applies the vertical taps, clips, looks the value up in the LDS
 //    copy of the table and writes planar [B, C, H, W] fp32 / bf16 with coalesced stores.
 #include "vit_common.h"
@@ -131,13 +131,14 @@ struct HParams {
     size_t in_bytes;  // total bytes of `in` (dword loads never cross it)
 };
 
+template <int C>
 __global__ __launch_bounds__(256) void resample_h_kernel(const HParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * ROWS_H;
     const int rows = min(ROWS_H, P.nrows - r0);
-    const int rowbytes = P.in_w * P.C;
+    const int rowbytes = P.in_w * C;
     const int lpitch = (rowbytes + 3 + 3) & ~3;  // staged row: up to 3 lead bytes + row, dword multiple
     unsigned int* sm32 = (unsigned int*)smem;
 
@@ -160,28 +161,40 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const HParams P) {
     }
     __syncthreads();
 
-    const int outbytes = P.ncols * P.C;
-    const int groups = (outbytes + 3) >> 2;  // 4 output bytes per work item
+    // work item = 4 adjacent output pixels of one row: the taps of a pixel are loaded once for its C
+    // channels, and the 4*C result bytes leave as C dword stores (tmp rows are 16-B pitched and hold
+    // whole 4-pixel groups, so the stores are aligned and inside the pitch)
+    const int groups = (P.ncols + 3) >> 2;
     for (int it = tid; it < rows * groups; it += 256) {
-        const int r = it / groups, j4 = (it - r * groups) * 4;
+        const int r = it / groups, g = it - r * groups;
         const size_t g0 = ((size_t)b * P.in_h + P.y0 + r0 + r) * rowbytes;
         const unsigned char* row = smem + r * lpitch + (int)(g0 & 3);
-        unsigned int packed = 0;
+        unsigned int val[4 * C];  // result bytes of the group, in tmp order (pixel-major, channel-minor)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = j4 + e;
-            if (j < outbytes) {
-                const int xo = j / P.C, c = j - xo * P.C;
-                const int xx = P.x0 + xo;
-                const int xmin = P.bounds[2 * xx], n = P.bounds[2 * xx + 1];
-                const int* k = P.coef + (size_t)xx * P.ksize;
-                int ss = 1 << (PRECISION_BITS - 1);
-                for (int x = 0; x < n; ++x) ss += (int)row[(xmin + x) * P.C + c] * k[x];
-                packed |= (unsigned int)clip8(ss) << (8 * e);
+        for (int px = 0; px < 4; ++px) {
+            const int xo = g * 4 + px;
+            const int xx = P.x0 + (xo < P.ncols ? xo : P.ncols - 1);  // tail pixels recompute the last one
+            const int xmin = P.bounds[2 * xx], n = P.bounds[2 * xx + 1];
+            const int* k = P.coef + (size_t)xx * P.ksize;
+            const unsigned char* src = row + xmin * C;
+            int ss[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) ss[c] = 1 << (PRECISION_BITS - 1);
+            for (int x = 0; x < n; ++x) {
+                const int kx = k[x];
+#pragma unroll
+                for (int c = 0; c < C; ++c) ss[c] += (int)src[x * C + c] * kx;
             }
+#pragma unroll
+            for (int c = 0; c < C; ++c) val[px * C + c] = (unsigned int)clip8(ss[c]);
         }
-        // tmp rows are 16-B pitched, so the 4-byte group is always dword aligned and inside the pitch
-        *(unsigned int*)(P.tmp + ((size_t)b * P.nrows + r0 + r) * P.tpitch + j4) = packed;
+        unsigned int packed[C];
+#pragma unroll
+        for (int d = 0; d < C; ++d)
+            packed[d] = val[4 * d] | (val[4 * d + 1] << 8) | (val[4 * d + 2] << 16) | (val[4 * d + 3] << 24);
+        unsigned int* dst = (unsigned int*)(P.tmp + ((size_t)b * P.nrows + r0 + r) * P.tpitch + (size_t)g * 4 * C);
+#pragma unroll
+        for (int d = 0; d < C; ++d) dst[d] = packed[d];
     }
 }
 
@@ -199,6 +212,8 @@ struct VParams {
     int out_h, out_w;
 };
 
+constexpr int ROWS_V = 4;  // output rows per workgroup
+
 template <typename T, int C>
 __global__ __launch_bounds__(256) void resample_v_kernel(const VParams P) {
     __shared__ float lut[C * 256];
@@ -206,28 +221,23 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const VParams P) {
     for (int i = tid; i < C * 256; i += 256) lut[i] = P.lut[i];
     __syncthreads();
 
-    const int y = blockIdx.x, b = blockIdx.y;
-    const int sy = y + P.top;
-    T* out = (T*)P.out + (size_t)b * C * P.out_h * P.out_w + (size_t)y * P.out_w;
+    const int y0 = blockIdx.x * ROWS_V, b = blockIdx.y;
+    const int rows = min(ROWS_V, P.out_h - y0);
     const size_t plane = (size_t)P.out_h * P.out_w;
+    T* outb = (T*)P.out + (size_t)b * C * plane;
 
-    if (sy < 0 || sy >= P.rs_h) {  // whole row is padding (image smaller than the crop)
-        for (int i = tid; i < C * P.out_w; i += 256) {
-            const int c = i / P.out_w, x = i - c * P.out_w;
-            out[c * plane + x] = (T)lut[c * 256];
-        }
-        return;
-    }
-    const int ymin = P.bounds[2 * sy], n = P.bounds[2 * sy + 1];
-    const int* k = P.coef + (size_t)sy * P.ksize;
-    const unsigned char* base = P.tmp + ((size_t)b * P.nrows + (ymin - P.y0)) * P.tpitch;
-
-    const int groups = (P.ncols + 3) >> 2;  // 4 pixels x C channels per work item = C dwords
-    for (int g = tid; g < groups; g += 256) {
+    // work item = 4 adjacent pixels x C channels (C dwords of the intermediate) of one output row
+    const int groups = (P.ncols + 3) >> 2;
+    for (int it = tid; it < rows * groups; it += 256) {
+        const int r = it / groups, g = it - r * groups;
+        const int y = y0 + r, sy = y + P.top;
+        if (sy < 0 || sy >= P.rs_h) continue;  // padding row, filled below
+        const int ymin = P.bounds[2 * sy], n = P.bounds[2 * sy + 1];
+        const int* k = P.coef + (size_t)sy * P.ksize;
+        const unsigned char* p = P.tmp + ((size_t)b * P.nrows + (ymin - P.y0)) * P.tpitch + (size_t)g * 4 * C;
         int acc[4 * C];
 #pragma unroll
         for (int e = 0; e < 4 * C; ++e) acc[e] = 1 << (PRECISION_BITS - 1);
-        const unsigned char* p = base + (size_t)g * 4 * C;
         for (int t = 0; t < n; ++t) {
             const int kt = k[t];
             const unsigned int* pw = (const unsigned int*)(p + (size_t)t * P.tpitch);
@@ -238,6 +248,7 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const VParams P) {
                 for (int e = 0; e < 4; ++e) acc[4 * d + e] += (int)((w >> (8 * e)) & 255u) * kt;
             }
         }
+        T* out = outb + (size_t)y * P.out_w;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             const int xo = g * 4 + px;            // column inside the kept range
@@ -248,13 +259,17 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const VParams P) {
             }
         }
     }
-    // columns left / right of the resized image: padding
-    const int xl = -P.left;                 // first output column that has data (if > 0)
-    const int xr = P.rs_w - P.left;         // one past the last output column with data
-    if (xl > 0 || xr < P.out_w) {
-        for (int i = tid; i < C * P.out_w; i += 256) {
-            const int c = i / P.out_w, x = i - c * P.out_w;
-            if (x < xl || x >= xr) out[c * plane + x] = (T)lut[c * 256];
+    // padding (image smaller than the crop, image_transforms.py:505-524): whole rows above / below the
+    // resized image, columns left / right of it
+    const int xl = -P.left;            // first output column that has data (if > 0)
+    const int xr = P.rs_w - P.left;    // one past the last output column with data
+    const bool any_row_pad = (y0 + P.top < 0) || (y0 + rows - 1 + P.top >= P.rs_h);
+    if (any_row_pad || xl > 0 || xr < P.out_w) {
+        for (int i = tid; i < rows * C * P.out_w; i += 256) {
+            const int r = i / (C * P.out_w), rem = i - r * (C * P.out_w);
+            const int c = rem / P.out_w, x = rem - c * P.out_w;
+            const int sy = y0 + r + P.top;
+            if (sy < 0 || sy >= P.rs_h || x < xl || x >= xr) outb[c * plane + (size_t)(y0 + r) * P.out_w + x] = (T)lut[c * 256];
         }
     }
 }
@@ -406,8 +421,12 @@ extern "C" int vit_preproc_run(vit_preproc* p, const void* images_dev, int batch
     H.y0 = p->y0; H.nrows = p->nrows; H.x0 = p->x0; H.ncols = p->ncols; H.tpitch = p->tpitch;
     H.in_bytes = (size_t)batch * c.in_height * c.in_width * c.channels;
     const int lpitch = (c.in_width * c.channels + 3 + 3) & ~3;
-    hipLaunchKernelGGL(resample_h_kernel, dim3(ceil_div(p->nrows, ROWS_H), batch), dim3(256), (size_t)ROWS_H * lpitch,
-                       stream, H);
+    if (c.channels == 1)
+        hipLaunchKernelGGL(resample_h_kernel<1>, dim3(ceil_div(p->nrows, ROWS_H), batch), dim3(256),
+                           (size_t)ROWS_H * lpitch, stream, H);
+    else
+        hipLaunchKernelGGL(resample_h_kernel<3>, dim3(ceil_div(p->nrows, ROWS_H), batch), dim3(256),
+                           (size_t)ROWS_H * lpitch, stream, H);
     VIT_CHECK_HIP(hipGetLastError());
 
     VParams V{};
@@ -416,7 +435,7 @@ extern "C" int vit_preproc_run(vit_preproc* p, const void* images_dev, int batch
     V.bounds = p->bounds_v; V.coef = p->coef_v; V.lut = p->lut; V.ksize = p->kv; V.C = c.channels;
     V.y0 = p->y0; V.nrows = p->nrows; V.x0 = p->x0; V.ncols = p->ncols; V.tpitch = p->tpitch;
     V.rs_h = p->rs_h; V.rs_w = p->rs_w; V.top = p->top; V.left = p->left; V.out_h = p->out_h; V.out_w = p->out_w;
-    dim3 grid(p->out_h, batch), block(256);
+    dim3 grid(ceil_div(p->out_h, ROWS_V), batch), block(256);
 #define PRE_V(T, CH) hipLaunchKernelGGL((resample_v_kernel<T, CH>), grid, block, 0, stream, V)
     if (out_dtype == VIT_F32) {
         if (c.channels == 1) PRE_V(float, 1); else PRE_V(float, 3);
