@@ -118,6 +118,11 @@ def test_linear_rejects_bad_shapes():
 ATTN_CASES = [  # batch, seq, heads, head_dim
     (2, 10, 2, 80), (3, 17, 4, 16), (2, 197, 12, 64), (1, 577, 4, 64), (1, 1025, 2, 80), (2, 33, 2, 128),
     (1, 1, 1, 32), (2, 32, 3, 64), (1, 225, 2, 64), (1, 300, 1, 48),
+    # head_dim 64 persistent LDS-DMA kernel: the eligibility edge (N = 96 falls back, 97 is the first
+    # taken), exact tile multiples, one and several query blocks with idle waves, more items than
+    # resident workgroups (37*16 = 592 items > 512) and fewer items than workgroups
+    (2, 96, 2, 64), (2, 97, 2, 64), (3, 128, 2, 64), (2, 129, 3, 64), (2, 256, 2, 64), (2, 257, 2, 64),
+    (37, 197, 16, 64), (1, 1025, 3, 64), (5, 161, 7, 64),
 ]
 
 

@@ -368,6 +368,10 @@ int launch_attn_f32(const void* qkv, void* out, int batch, int N, int H, hipStre
 
 }  // namespace
 
+// persistent LDS-DMA kernel for head_dim 64 (attention_dh64.hip)
+bool attention_dh64_eligible(int N);
+int launch_attention_dh64(const void* qkv, void* out, float* lse, int batch, int N, int H, hipStream_t stream);
+
 int launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, int dtype,
                      hipStream_t stream, float* lse) {
     VIT_REQUIRE(batch > 0 && seq > 0 && heads > 0, "attention: empty problem");
@@ -375,6 +379,8 @@ int launch_attention(const void* qkv, void* out, int batch, int seq, int heads, 
                 "attention: head_dim must be a multiple of 16 in [16,128], got %d", head_dim);
     VIT_REQUIRE(dtype == VIT_BF16 || dtype == VIT_F32, "attention: bad dtype %d", dtype);
     VIT_REQUIRE(lse == nullptr || dtype == VIT_BF16, "attention: the log-sum-exp output is bf16-mode only");
+    if (dtype == VIT_BF16 && head_dim == 64 && attention_dh64_eligible(seq))
+        return launch_attention_dh64(qkv, out, lse, batch, seq, heads, stream);
 #define ATTN_CASE(DHV)                                                                          \
     case DHV:                                                                                   \
         return dtype == VIT_BF16 ? launch_attn_bf16<DHV>(qkv, out, lse, batch, seq, heads, stream) \
