@@ -80,7 +80,9 @@ def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
         ("gemm_o_proj_res", L, lambda: ops.linear(x, wo, bo, residual=x), 2 * m * d * d, None),
         ("gemm_fc1_gelu", L, lambda: ops.linear(x, w1, b1, activation=cfg.hidden_act), 2 * m * f * d, None),
         ("gemm_fc2_res", L, lambda: ops.linear(hid, w2, bo, residual=x), 2 * m * d * f, None),
-        ("attention", L, lambda: ops.attention(qkv, h), 4 * batch * h * n * n * cfg.head_dim, None),
+        # attention at N = 197, dh = 64 is 99 FLOP per byte (Q, K, V read once, output written once)
+        # against a machine balance of ~310: its roofline is HBM; both figures are reported
+        ("attention", L, lambda: ops.attention(qkv, h), 4 * batch * h * n * n * cfg.head_dim, 4 * m * d * 2),
         ("layernorm", 2 * L + 1, lambda: ops.layer_norm(x, g, b, cfg.layer_norm_eps), None, 2 * m * d * 2),
         ("patch_embed", 1, lambda: ops.patch_embed(px, pw, bo, cls, pos, cfg.patch_size),
          2 * batch * cfg.num_patches * cfg.patch_dim * d, None),
@@ -88,7 +90,12 @@ def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
     out = {}
     for name, per_fwd, fn, flops, nbytes in specs:
         dt = time_kernel(fn)
-        if flops is not None:
+        if flops is not None and nbytes is not None:
+            out[name] = {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": nbytes / dt / HBM_PEAK, "mfma_tflops": flops / dt / 1e12,
+                         "mfma_frac": flops / dt / MFMA_BF16_PEAK, "us_per_launch": dt * 1e6,
+                         "launches_per_forward": per_fwd}
+        elif flops is not None:
             ach = flops / dt
             out[name] = {"bound": "mfma", "achieved": ach / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": ach / MFMA_BF16_PEAK, "us_per_launch": dt * 1e6, "launches_per_forward": per_fwd}
