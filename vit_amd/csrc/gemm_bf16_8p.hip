@@ -319,7 +319,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                             for (int e = 0; e < 4; ++e) pv[e] = (bf16_t)v[e];
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pv), Pr, (int)voff, 0, 0);
                         }
-                        if constexpr (EPI == VIT_EPI_GELU || EPI == VIT_EPI_QUICK_GELU) {
+                        if constexpr (EPI == VIT_EPI_GELU) {
+                            const f32x2 g0 = act_gelu_pk(f32x2{v[0], v[1]}), g1 = act_gelu_pk(f32x2{v[2], v[3]});
+                            v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+                        }
+                        if constexpr (EPI == VIT_EPI_QUICK_GELU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = apply_act_bf16<EPI>(v[e]);
                         }

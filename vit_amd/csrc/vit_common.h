@@ -54,6 +54,34 @@ __device__ __forceinline__ float act_gelu_as(float x) {
     return fmaxf(x, 0.0f) - ax * p;
 }
 
+// GELU on two elements at once for the persistent GEMM's epilogue, where the activation is the
+// exposed cost (128 elements per lane and tile): no transcendental, and the multiplies / FMAs
+// are written on float2 so they become v_pk_mul_f32 / v_pk_fma_f32 (2 elements per issue).
+//   erf(z) = z h(z^2) with h a degree-8 minimax-style fit on z^2 in [0, 9] (Chebyshev-node least
+//   squares), z^2 clamped to 9 and the product clamped to [-1, 1], so both tails are exact.
+// |gelu error| <= 7.7e-5 over all x (largest near |x| = 4, where one bf16 ulp of the result is
+// 1.6e-2; <= 2e-5 for |x| <= 2), i.e. below the bf16 rounding of the stored activation.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 act_gelu_pk(f32x2 x) {
+    const f32x2 z = x * 0.70710678118654752440f;
+    f32x2 u = z * z;
+    u.x = fminf(u.x, 9.0f);
+    u.y = fminf(u.y, 9.0f);
+    f32x2 p = u * 4.9182759198629356e-08f + -2.2677306787954876e-06f;
+    p = p * u + 4.6147291868692264e-05f;
+    p = p * u + -0.0005535572418011725f;
+    p = p * u + 0.004437862429767847f;
+    p = p * u + -0.02564961276948452f;
+    p = p * u + 0.11186250299215317f;
+    p = p * u + -0.3758186101913452f;
+    p = p * u + 1.1283628940582275f;
+    f32x2 s = z * p;
+    s.x = __builtin_amdgcn_fmed3f(s.x, -1.0f, 1.0f);
+    s.y = __builtin_amdgcn_fmed3f(s.y, -1.0f, 1.0f);
+    const f32x2 t = x * 0.5f;
+    return t * s + t;
+}
+
 // gelu'(x) = Phi(x) + x phi(x), same erfc approximation (backward of ViTMLP's activation)
 __device__ __forceinline__ float act_dgelu_as(float x) {
     const float ax = fabsf(x);
