@@ -6,6 +6,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -210,6 +211,24 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
         w.wqkv = A + lo[l].wqkv; w.wo = A + lo[l].wo; w.w1 = A + lo[l].w1; w.w2 = A + lo[l].w2;
     }
     ctx->n_missing = (int)ctx->slots.size();
+    // two-stream forward: on by default for bf16 contexts, VIT_AMD_DUAL_STREAM=0/1 overrides
+    ctx->ev_fork = nullptr;
+    for (int i = 0; i < vit_ctx::kMaxStreams - 1; ++i) { ctx->aux_stream[i] = nullptr; ctx->ev_join[i] = nullptr; }
+    const char* ds = getenv("VIT_AMD_STREAMS");
+    ctx->nstreams = ds ? atoi(ds) : (c.dtype == VIT_BF16 ? 2 : 1);
+    if (ctx->nstreams < 1) ctx->nstreams = 1;
+    if (ctx->nstreams > vit_ctx::kMaxStreams) ctx->nstreams = vit_ctx::kMaxStreams;
+    if (ctx->nstreams > 1) {
+        e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+        for (int i = 0; i < ctx->nstreams - 1 && e == hipSuccess; ++i) {
+            e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            vit_destroy(ctx);
+            return vit_set_error(VIT_E_HIP, "vit_create: stream / event creation failed: %s", hipGetErrorString(e));
+        }
+    }
     *out = ctx;
     return VIT_OK;
 }
@@ -217,6 +236,11 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
 extern "C" int vit_destroy(vit_ctx* ctx) {
     if (!ctx) return VIT_OK;
     vit_train_free(ctx);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int i = 0; i < vit_ctx::kMaxStreams - 1; ++i) {
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+        if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]);
+    }
     if (ctx->arena) (void)hipFree(ctx->arena);
     delete ctx;
     return VIT_OK;
@@ -275,9 +299,21 @@ Workspace plan_workspace(const vit_ctx* ctx, int batch) {
 }
 }  // namespace
 
+// A batch is cut into up to ctx->nstreams contiguous chunks of at least kMinChunk images, one stream each
+static const int kMinChunk = 32;
+static int num_chunks(const vit_ctx* ctx, int batch) {
+    int k = ctx->nstreams;
+    while (k > 1 && batch / k < kMinChunk) --k;
+    return k;
+}
+static int chunk_begin(int batch, int k, int i) { return (int)((long)batch * i / k); }
+
 extern "C" size_t vit_workspace_bytes(const vit_ctx* ctx, int batch) {
     if (!ctx || batch <= 0) return 0;
-    return plan_workspace(ctx, batch).total;
+    const int k = num_chunks(ctx, batch);
+    size_t total = 0;
+    for (int i = 0; i < k; ++i) total += plan_workspace(ctx, chunk_begin(batch, k, i + 1) - chunk_begin(batch, k, i)).total;
+    return total;
 }
 
 #define VIT_TRY(expr)                 \
@@ -285,6 +321,9 @@ extern "C" size_t vit_workspace_bytes(const vit_ctx* ctx, int batch) {
         int _rc = (expr);             \
         if (_rc != VIT_OK) return _rc; \
     } while (0)
+
+static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
+                         void* pooled_out, void* workspace, hipStream_t stream);
 
 extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
                            void* pooled_out, void* workspace, size_t workspace_bytes, void* stream_) {
@@ -299,11 +338,41 @@ extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype
     VIT_CHECK_HIP(hipGetDevice(&dev));
     if (dev != ctx->device)
         return vit_set_error(VIT_E_STATE, "vit_forward: context lives on device %d, current device is %d", ctx->device, dev);
-    const Workspace w = plan_workspace(ctx, batch);
-    if (workspace_bytes < w.total)
-        return vit_set_error(VIT_E_NOMEM, "vit_forward: workspace %zu < required %zu bytes", workspace_bytes, w.total);
-
+    const size_t need = vit_workspace_bytes(ctx, batch);
+    if (workspace_bytes < need)
+        return vit_set_error(VIT_E_NOMEM, "vit_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
     hipStream_t stream = (hipStream_t)stream_;
+    const int k = num_chunks(ctx, batch);
+    if (k == 1) return forward_range(ctx, pixels_dev, pixel_dtype, batch, hidden_out, pooled_out, workspace, stream);
+
+    // chunks on separate streams: fork after whatever the caller queued, join before returning control.
+    // One chunk's kernels fill the CUs that another chunk's last round of tiles leaves idle.
+    const vit_config& c = ctx->cfg;
+    const size_t es = esize(c.dtype), pes = esize(pixel_dtype);
+    const size_t img = (size_t)c.num_channels * c.image_size * c.image_size;
+    VIT_CHECK_HIP(hipEventRecord(ctx->ev_fork, stream));
+    size_t ws_off = 0;
+    for (int i = 0; i < k; ++i) {
+        const int b0 = chunk_begin(batch, k, i), nb = chunk_begin(batch, k, i + 1) - b0;
+        hipStream_t st = i == 0 ? stream : ctx->aux_stream[i - 1];
+        if (i > 0) VIT_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+        VIT_TRY(forward_range(ctx, (const char*)pixels_dev + (size_t)b0 * img * pes, pixel_dtype, nb,
+                              (char*)hidden_out + (size_t)b0 * ctx->N * c.hidden_size * es,
+                              pooled_out ? (char*)pooled_out + (size_t)b0 * c.hidden_size * es : nullptr,
+                              (char*)workspace + ws_off, st));
+        ws_off += plan_workspace(ctx, nb).total;
+        if (i > 0) {
+            VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[i - 1], st));
+            VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[i - 1], 0));
+        }
+    }
+    return VIT_OK;
+}
+
+// the whole forward of `batch` images on one stream
+static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
+                         void* pooled_out, void* workspace, hipStream_t stream) {
+    const Workspace w = plan_workspace(ctx, batch);
     const vit_config& c = ctx->cfg;
     const int T = c.dtype, D = c.hidden_size, F = c.intermediate_size, N = ctx->N, H = c.num_attention_heads;
     const int M = batch * N;
