@@ -147,3 +147,30 @@ def test_determinism_repeat_runs():
     a = enc(px).last_hidden_state.clone()
     for _ in range(3):
         assert torch.equal(enc(px).last_hidden_state, a)
+
+
+@pytest.mark.gpu
+def test_two_stream_forward_equals_single_stream(monkeypatch):
+    """vit_forward cuts batches >= 64 into two halves on two streams (VIT_AMD_STREAMS, read at vit_create).
+    Images are independent and the kernels deterministic: the outputs must be bit-identical to the
+    single-stream run, for an odd batch (uneven halves) and back-to-back calls on the same workspace."""
+    import torch
+    from vit_amd import synth
+    from vit_amd.config import ViTConfig
+    from vit_amd.encoder import ViTEncoder
+    cfg = ViTConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+    sd = synth.synthetic_state_dict(cfg, seed=0)
+    px = synth.synthetic_images(cfg, 71, seed=1).cuda().to(torch.bfloat16)
+    outs = []
+    for k in ("1", "2", "3"):
+        monkeypatch.setenv("VIT_AMD_STREAMS", k)
+        enc = ViTEncoder(cfg, dtype=torch.bfloat16, device="cuda:0")
+        enc.load_state_dict(sd)
+        a = enc(px)
+        b = enc(px)  # second call reuses the workspace while nothing else synchronises in between
+        torch.cuda.synchronize()
+        assert torch.equal(a.last_hidden_state, b.last_hidden_state)
+        outs.append((a.last_hidden_state.clone(), a.pooler_output.clone()))
+        enc.close()
+    for h, p in outs[1:]:
+        assert torch.equal(h, outs[0][0]) and torch.equal(p, outs[0][1])
