@@ -174,3 +174,35 @@ def test_two_stream_forward_equals_single_stream(monkeypatch):
         enc.close()
     for h, p in outs[1:]:
         assert torch.equal(h, outs[0][0]) and torch.equal(p, outs[0][1])
+
+
+@pytest.mark.gpu
+def test_forward_under_graph_capture():
+    """vit_forward allocates nothing and forks / joins its second stream with events, so a warmed-up call
+    can be captured into a HIP graph (torch.cuda.graph) and replayed on new pixel values."""
+    import torch
+    from vit_amd import synth
+    from vit_amd.config import ViTConfig
+    from vit_amd.encoder import ViTEncoder
+    cfg = ViTConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+    enc = ViTEncoder(cfg, dtype=torch.bfloat16, device="cuda:0")
+    enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0))
+    px = synth.synthetic_images(cfg, 70, seed=1).cuda().to(torch.bfloat16)
+    px2 = synth.synthetic_images(cfg, 70, seed=2).cuda().to(torch.bfloat16)
+    static_in = px.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up outside capture: one-time attribute / occupancy queries, workspace
+        enc(static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = enc(static_in)
+    static_in.copy_(px2)
+    g.replay()
+    torch.cuda.synchronize()
+    want = enc(px2)
+    torch.cuda.synchronize()
+    assert torch.equal(out.last_hidden_state, want.last_hidden_state)
+    assert torch.equal(out.pooler_output, want.pooler_output)
