@@ -1,0 +1,214 @@
+// Weight-gradient GEMM without transposes:  dW[m, n] = sum_t dY[t, m] * X[t, n]   (fp32 out)
+//
+// Backward of nn.Linear (modeling_vit.py:216-218, 236, 250-252) with respect to the weight; the
+// reduction runs over TOKENS, and both operands are token-major ([T, features], exactly as the
+// backward produces dY and the forward stashed X). The persistent GEMM of gemm_bf16_8p.hip wants
+// both operands K-contiguous, which cost two transposes per weight gradient (15 % of the training
+// step); this kernel reads the token-major tiles as they are and transposes inside the LDS read:
+//
+//  * tile 256 (m) x 256 (n) x 64 tokens, 8 waves (2 x 4), wave tile 128 x 64, one workgroup per CU,
+//    two LDS buffers of [64 tokens][256 features] per operand, fed by buffer-resource LDS-DMA
+//    (rows past T are outside the resource and read as zero: no padded copies), one barrier per
+//    K-tile, the next tile's DMA under the current tile's MFMAs.
+//  * MFMA fragments (16 features x 32 tokens, 8 consecutive tokens per lane) come out of the
+//    token-major tile through ds_read_b64_tr_b16: a 16-lane group loads 4 token rows x 16 features
+//    and each lane receives one feature's 4 tokens. 8 token rows x 32 bytes are read per LDS cycle,
+//    so the 32-byte feature block index is XOR-swizzled with f(t) = (t & 3) | ((t >> 3) & 1) << 2 --
+//    applied on the DMA's SOURCE address -- which makes those 8 segments cover all 64 banks.
+//  * split-K over tokens (few output tiles: 9 .. 144), one fp32 slab per split, summed in a fixed
+//    order by reduce_slabs (reproducible); the bias gradient (column sums of dY) rides along as one
+//    extra MFMA against a fragment of ones in the waves that own the first n-tile, and is added to
+//    db with one fp32 atomic per feature and workgroup (as the transpose kernel did before).
+#include "vit_common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE_BYTES = BK * BM * 2;      // 32 KB: one operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;    // A then B
+constexpr int LDS_BYTES = 2 * BUF_BYTES;     // two buffers
+
+struct TnParams {
+    const bf16_t* A;   // dY [T, Mo]
+    const bf16_t* B;   // X  [T, No]
+    float* slabs;      // [splits][Mo][No]
+    float* dbias;      // [Mo] or null (accumulated)
+    int T, Mo, No;
+    int tiles_m, tiles_n;
+    int tok_per_split;  // multiple of 64
+};
+
+__device__ __forceinline__ int swz(int t) { return (t & 3) | (((t >> 3) & 1) << 2); }
+
+// two transposed reads (token rows +0..3 and +4..7) of one fragment; no wait
+#define TR2(lo, hi, addr, off)                                                                        \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"         \
+                 : "=&v"(lo), "=&v"(hi)                                                               \
+                 : "v"(addr), "n"(off), "n"((off) + 2048)                                             \
+                 : "memory")
+
+__global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned smem_lds = (unsigned)(uintptr_t)LDS_PTR(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int q = lane >> 4, i16 = lane & 15;
+
+    const int tiles = P.tiles_m * P.tiles_n;
+    const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+    const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int t_begin = split * P.tok_per_split;
+    const int nk = P.tok_per_split / BK;
+
+    // ---- DMA staging: wave w, piece j covers token rows 2*(4w + j) + (lane >> 5), 16-byte chunk lane & 31
+    const __amdgpu_buffer_rsrc_t Ar =
+        __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (unsigned)P.T * (unsigned)P.Mo * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Br =
+        __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (unsigned)P.T * (unsigned)P.No * 2u, 0x00020000);
+    unsigned a_src[4], b_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 2 * (4 * wave + j) + (lane >> 5);
+        const int p = lane & 31;
+        const int c = ((((p >> 1) ^ swz(r)) << 1) | (p & 1)) * 8;  // first feature of the chunk this lane fetches
+        a_src[j] = (m0 + c < P.Mo) ? (unsigned)(r * P.Mo + m0 + c) * 2u : 0x80000000u;
+        b_src[j] = (n0 + c < P.No) ? (unsigned)(r * P.No + n0 + c) * 2u : 0x80000000u;
+    }
+    auto stage = [&](int buf, int kt) {
+        unsigned char* d = smem + buf * BUF_BYTES + wave * 4096;
+        const int tok = t_begin + kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, LDS_PTR(d + j * 1024), 16, (int)a_src[j], tok * P.Mo * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, LDS_PTR(d + TILE_BYTES + j * 1024), 16, (int)b_src[j],
+                                                     tok * P.No * 2, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses (LDS byte addresses, buffer 0, k-step 0, first half) ----
+    const int f = (i16 >> 2) | ((q & 1) << 2);  // = swz(token row) of every row this lane reads
+    const unsigned rowpart = (unsigned)((8 * q + (i16 >> 2)) * 512 + 8 * (i16 & 3));
+    unsigned a_off[8], b_off[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) a_off[mi] = smem_lds + rowpart + (unsigned)(((wm * 8 + mi) ^ f) * 32);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b_off[ni] = smem_lds + TILE_BYTES + rowpart + (unsigned)(((wn * 4 + ni) ^ f) * 32);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (P.dbias != nullptr) && tn == 0 && wn == 0;  // wave-uniform
+    f32x4 bacc[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) bacc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // tile kt landed; buffer buf^1 is free again
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        const unsigned bo = (unsigned)(buf * BUF_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            short4v bl[4], bh[4], al[8], ah[8];
+            // B fragments and the first four A fragments, then the other four A under the first MFMAs
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                if (ks == 0) TR2(bl[ni], bh[ni], b_off[ni] + bo, 0); else TR2(bl[ni], bh[ni], b_off[ni] + bo, 16384);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if (ks == 0) TR2(al[mi], ah[mi], a_off[mi] + bo, 0); else TR2(al[mi], ah[mi], a_off[mi] + bo, 16384);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]),
+                           "+v"(bh[3]), "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]),
+                           "+v"(al[3]), "+v"(ah[3])::"memory");
+#pragma unroll
+            for (int mi = 4; mi < 8; ++mi) {
+                if (ks == 0) TR2(al[mi], ah[mi], a_off[mi] + bo, 0); else TR2(al[mi], ah[mi], a_off[mi] + bo, 16384);
+            }
+            bf16x8 bfr[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                bfr[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(bl[ni], bh[ni], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const bf16x8 afr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[mi], ah[mi], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
+                if (do_bias) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(al[4]), "+v"(ah[4]), "+v"(al[5]), "+v"(ah[5]), "+v"(al[6]), "+v"(ah[6]), "+v"(al[7]),
+                           "+v"(ah[7])::"memory");
+#pragma unroll
+            for (int mi = 4; mi < 8; ++mi) {
+                const bf16x8 afr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[mi], ah[mi], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
+                if (do_bias) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: D = (X^T-fragment rows n) x (dY^T-fragment cols m): lane holds m = lane & 15 and the
+    // four consecutive n = 4 * (lane >> 4) + e  ->  one 16-byte store per fragment
+    float* slab = P.slabs + (size_t)split * P.Mo * P.No;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + wm * 128 + mi * 16 + i16;
+        if (m < P.Mo) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + 4 * q;
+                if (n < P.No) *(f32x4*)(slab + (size_t)m * P.No + n) = acc[mi][ni];
+            }
+        }
+    }
+    if (do_bias && q == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wm * 128 + mi * 16 + i16;
+            if (m < P.Mo) atomicAdd(P.dbias + m, bacc[mi][0]);
+        }
+    }
+}
+
+}  // namespace
+
+int launch_reduce_slabs(const float* slabs, float* out, int splits, int64_t n, hipStream_t stream);
+
+// dW (fp32 [Mo, No]) = dY^T X over T tokens; db (fp32 [Mo], may be null) += column sums of dY.
+// slabs: splits * Mo * No floats of scratch when splits > 1.
+int launch_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* db, float* slabs, int T, int Mo, int No,
+                        int splits, hipStream_t stream) {
+    VIT_REQUIRE(T > 0 && Mo > 0 && No > 0 && splits >= 1, "gemm_tn: bad shape T=%d Mo=%d No=%d splits=%d", T, Mo, No, splits);
+    VIT_REQUIRE(Mo % 8 == 0 && No % 8 == 0, "gemm_tn: feature counts must be multiples of 8 (Mo=%d No=%d)", Mo, No);
+    VIT_REQUIRE((long)T * (Mo > No ? Mo : No) * 2 < (1L << 31), "gemm_tn: an operand exceeds 2 GiB");
+    VIT_REQUIRE(splits == 1 || slabs != nullptr, "gemm_tn: split-K needs the slab scratch");
+    static bool attr_set = false;
+    if (!attr_set) {
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    TnParams P{};
+    P.A = (const bf16_t*)dY; P.B = (const bf16_t*)X; P.dbias = db;
+    P.slabs = splits > 1 ? slabs : dW;
+    P.T = T; P.Mo = Mo; P.No = No;
+    P.tiles_m = ceil_div(Mo, BM); P.tiles_n = ceil_div(No, BN);
+    P.tok_per_split = ceil_div(ceil_div(T, splits), BK) * BK;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(P.tiles_m * P.tiles_n * splits), dim3(512), LDS_BYTES, stream, P);
+    VIT_CHECK_HIP(hipGetLastError());
+    if (splits > 1) return launch_reduce_slabs(slabs, dW, splits, (int64_t)Mo * No, stream);
+    return VIT_OK;
+}

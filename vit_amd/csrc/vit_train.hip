@@ -30,6 +30,9 @@ struct TrainState {
     std::vector<LayerT> layers;
 };
 
+int launch_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* db, float* slabs, int T, int Mo, int No,
+                        int splits, hipStream_t stream);  // gemm_tn_bf16.hip
+
 namespace {
 
 #define VIT_TRY(expr)                  \
@@ -136,6 +139,11 @@ int wgrad(const vit_ctx* ctx, const TGeo& g, unsigned char* ws, const TWork& w, 
           const void* X, int cols_out, int Mtok, int group_dy, float* dw, float* db, hipStream_t stream,
           const void* x_pre_transposed = nullptr) {
     int splits = g.big ? wgrad_splits(rows_out, cols_out) : 1;
+    if (group_dy == 0 && x_pre_transposed == nullptr) {
+        // token-major operands as they are: transposing MFMA kernel (gemm_tn_bf16.hip), bias gradient fused
+        if (Mtok / splits < 256) splits = 1;
+        return launch_gemm_tn_bf16(dY, X, dw, db, (float*)(ws + w.slabs), Mtok, rows_out, cols_out, splits, stream);
+    }
     if ((long)rows_out * cols_out * splits < 64L * 256 * 256) splits = 1;  // too small for the persistent kernel
     const int mp = round_up(Mtok, 128 * splits);
     if (mp / splits < 256) splits = 1;
