@@ -178,6 +178,14 @@ int vit_layernorm_bwd(const void* x, const void* dy, const float* gamma, const v
  * group is skipped (token rows without CLS). C % 8 == 0, Rpad % 8 == 0. */
 int vit_transpose_pad(const void* src, void* dst, float* colsum, int R, int C, int Rpad, int group, void* stream);
 
+/* Weight / bias gradient of nn.Linear (backward of MV:216-218, 236, 250-252): dW[out, in] (fp32) =
+ * dY^T X over `tokens` rows, db[out] (fp32, may be NULL) += column sums of dY. dY [tokens, out] and
+ * X [tokens, in] are bf16 row-major exactly as the backward / the stash hold them: no transposed
+ * copies. splits > 1 cuts the token range into that many parts, one fp32 slab each in `slabs`
+ * (splits * out * in floats), summed in a fixed order. out % 8 == 0, in % 8 == 0. */
+int vit_linear_wgrad(const void* dY, const void* X, float* dW, float* db, float* slabs, int tokens, int out_features,
+                     int in_features, int splits, void* stream);
+
 /* ---- whole training step (VIT_BF16 contexts). Buffers are caller-owned device memory:
  *   stash      vit_train_stash_bytes(ctx, batch): activations the backward re-reads
  *   workspace  vit_train_workspace_bytes(ctx, batch): scratch of forward_train and backward

@@ -107,3 +107,37 @@ def test_attention_backward(b, n, h, dh):
         assert cosine(got_j, ref_j) >= 0.999, (name, cosine(got_j, ref_j))
     # bitwise reproducible
     assert torch.equal(dqkv, ops.attention_backward(qkv.to(DEV), out, d_out.to(DEV), lse, h))
+
+
+@pytest.mark.parametrize("tokens,out_f,in_f,splits", [
+    (51, 64, 128, 1),        # fewer tokens than one 64-token tile: rows past T must read as zero
+    (64, 8, 8, 1),           # smallest legal features
+    (197 * 3, 768, 768, 1),  # ragged tokens, exact 256-tiles
+    (1000, 264, 520, 3),     # ragged tiles in both feature dims, splits that do not divide the token count
+    (4096, 2304, 768, 4), (8320, 768, 3072, 7), (8320, 3072, 768, 5),
+])
+def test_linear_wgrad_token_major(tokens, out_f, in_f, splits):
+    """vit_linear_wgrad (transposing MFMA kernel) against fp32 dY^T X / column sums on the same bf16 operands."""
+    import torch
+    from vit_amd import _lib, synth
+    lib = _lib.load()
+    dev = "cuda:0"
+    dy = synth.normal((tokens, out_f), 5, "dy").to(dev, torch.bfloat16)
+    x = synth.normal((tokens, in_f), 5, "x").to(dev, torch.bfloat16)
+    dw = torch.full((out_f, in_f), float("nan"), device=dev)
+    db = torch.ones(out_f, device=dev)  # accumulated into
+    slabs = torch.full((splits * out_f * in_f,), float("nan"), device=dev)
+    _lib.check(lib.vit_linear_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), slabs.data_ptr(), tokens,
+                                    out_f, in_f, splits, None))
+    torch.cuda.synchronize()
+    want = dy.float().t() @ x.float()
+    wantb = 1.0 + dy.float().sum(0)
+    scale = want.abs().max().item()
+    assert (dw - want).abs().max().item() <= 2e-4 * scale + 1e-3  # fp32 accumulation of exact bf16 products
+    assert (db - wantb).abs().max().item() <= 2e-4 * wantb.abs().max().item() + 1e-3
+    # reproducible: the slab sum runs in a fixed order (bias uses atomics and is excluded)
+    dw2 = torch.empty_like(dw)
+    _lib.check(lib.vit_linear_wgrad(dy.data_ptr(), x.data_ptr(), dw2.data_ptr(), None, slabs.data_ptr(), tokens,
+                                    out_f, in_f, splits, None))
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)

@@ -70,6 +70,7 @@ SIGNATURES = {
     "vit_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_float, c_void_p]),
     "vit_transpose_pad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vit_linear_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vit_train_stash_bytes": (c_size_t, [c_void_p, c_int]),
     "vit_train_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "vit_grad_bytes": (c_size_t, [c_void_p]),

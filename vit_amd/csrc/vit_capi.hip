@@ -508,6 +508,15 @@ extern "C" int vit_layernorm_bwd(const void* x, const void* dy, const float* gam
                                 (hipStream_t)stream);
 }
 
+int launch_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* db, float* slabs, int T, int Mo, int No,
+                        int splits, hipStream_t stream);  // gemm_tn_bf16.hip
+
+extern "C" int vit_linear_wgrad(const void* dY, const void* X, float* dW, float* db, float* slabs, int tokens,
+                                int out_features, int in_features, int splits, void* stream) {
+    VIT_REQUIRE(dY && X && dW, "vit_linear_wgrad: null argument");
+    return launch_gemm_tn_bf16(dY, X, dW, db, slabs, tokens, out_features, in_features, splits, (hipStream_t)stream);
+}
+
 extern "C" int vit_transpose_pad(const void* src, void* dst, float* colsum, int R, int C, int Rpad, int group,
                                  void* stream) {
     VIT_REQUIRE(src && dst, "vit_transpose_pad: null argument");
