@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int rows, int dim, int64_t xs, int64_t dys, int64_t dxs,
-                                                            float eps) {
+                                                            float eps, float* __restrict__ partials) {
     __shared__ float red[2][4][NIT * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_in_grid = blockIdx.x * 4 + wave;
@@ -164,9 +164,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     for (int c = threadIdx.x; c < dim; c += 256) {
         const float g = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
         const float b = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-        atomicAdd(dgamma + c, g);
-        atomicAdd(dbeta + c, b);
+        if (partials != nullptr) {  // [block][2][dim], summed by ln_bwd_reduce_kernel (32 atomics per column, not 2048)
+            partials[((size_t)blockIdx.x * 2 + 0) * dim + c] = g;
+            partials[((size_t)blockIdx.x * 2 + 1) * dim + c] = b;
+        } else {
+            atomicAdd(dgamma + c, g);
+            atomicAdd(dbeta + c, b);
+        }
     }
+}
+
+// second stage of the dgamma / dbeta reduction: grid (ceil(2*dim / 256), chunks); a block sums its chunk of
+// the per-block partials for 256 columns and adds the result with one atomic per column
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nblocks, int dim,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int col = blockIdx.x * 256 + threadIdx.x;  // 0 .. 2*dim: gamma columns then beta columns
+    if (col >= 2 * dim) return;
+    const int which = col >= dim ? 1 : 0, c = col - which * dim;
+    const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += partials[((size_t)b * 2 + which) * dim + c];
+    if (b1 > b0) atomicAdd((which ? dbeta : dgamma) + c, s);
 }
 
 // ------------------------------------------------------------------ embedding gradients
@@ -270,22 +289,27 @@ int launch_transpose_pad(const void* src, void* dst, float* colsum, int R, int C
 
 int launch_layernorm_bwd(const void* x, const void* dy, const float* gamma, const void* dres, void* dx, float* dgamma,
                          float* dbeta, int rows, int dim, int64_t xs, int64_t dys, int64_t dxs, float eps,
-                         hipStream_t stream) {
+                         hipStream_t stream, float* partials) {
     VIT_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && dim <= 2048, "layernorm_bwd: bad shape rows=%d dim=%d", rows, dim);
     const int nit = ceil_div(dim, 256);
     int blocks = ceil_div(rows, 4);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > kLnBwdMaxBlocks) blocks = kLnBwdMaxBlocks;
 #define LNB_CASE(NI)                                                                                               \
     case NI:                                                                                                       \
         hipLaunchKernelGGL(layernorm_bwd_kernel<NI>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x,         \
                            (const bf16_t*)dy, gamma, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows, dim, xs, \
-                           dys, dxs, eps);                                                                         \
+                           dys, dxs, eps, partials);                                                               \
         break;
     switch (nit) {
         LNB_CASE(1) LNB_CASE(2) LNB_CASE(3) LNB_CASE(4) LNB_CASE(5) LNB_CASE(6) LNB_CASE(7) LNB_CASE(8)
     }
 #undef LNB_CASE
     VIT_CHECK_HIP(hipGetLastError());
+    if (partials != nullptr) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * dim, 256), 32), dim3(256), 0, stream, partials, blocks, dim,
+                           dgamma, dbeta);
+        VIT_CHECK_HIP(hipGetLastError());
+    }
     return VIT_OK;
 }
 

@@ -161,7 +161,9 @@ int launch_transpose_pad(const void* src, void* dst, float* colsum, int R, int C
                          hipStream_t stream);
 int launch_layernorm_bwd(const void* x, const void* dy, const float* gamma, const void* dres, void* dx, float* dgamma,
                          float* dbeta, int rows, int dim, int64_t xs, int64_t dys, int64_t dxs, float eps,
-                         hipStream_t stream);
+                         hipStream_t stream, float* partials = nullptr);
+// layernorm_bwd `partials`: optional scratch of kLnBwdMaxBlocks * 2 * dim floats for a two-stage dgamma / dbeta sum
+constexpr int kLnBwdMaxBlocks = 2048;
 int launch_embed_grad(const void* dx0, float* dpos, float* dcls, int B, int N, int D, hipStream_t stream);
 int launch_sgd(float* master, const float* grad, void* copy_bf16, float lr, int64_t n, hipStream_t stream);
 int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t stream);

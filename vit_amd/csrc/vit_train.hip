@@ -97,7 +97,7 @@ Stash plan_stash(const vit_ctx* ctx, int batch) {
 }
 
 struct TWork {  // byte offsets
-    size_t dx, dx2, dln, du, dqkv, t1, t2, delta, slabs, pix, total;
+    size_t dx, dx2, dln, du, dqkv, t1, t2, delta, slabs, pix, lnred, total;
     int mp_max;  // largest padded token count any transpose uses
 };
 TWork plan_twork(const vit_ctx* ctx, int batch) {
@@ -128,6 +128,7 @@ TWork plan_twork(const vit_ctx* ctx, int batch) {
     }
     w.slabs = take(slab);
     w.pix = take((size_t)batch * ctx->cfg.num_channels * ctx->cfg.image_size * ctx->cfg.image_size * 2);
+    w.lnred = take((size_t)kLnBwdMaxBlocks * 2 * g.D * 4);
     w.total = cur;
     return w;
 }
@@ -360,7 +361,7 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
             // folds d_pooled into d_hidden's CLS rows
             VIT_REQUIRE(d_pooled == nullptr, "vit_backward_stage: ViT variant: add d_pooled to the CLS rows of d_hidden");
             VIT_TRY(launch_layernorm_bwd(xl, d_hidden, ctx->fin_g, nullptr, dx, G + ctx->g_fin_g, G + ctx->g_fin_b, g.M, g.D,
-                                         g.D, g.D, g.D, c.layer_norm_eps, stream));
+                                         g.D, g.D, g.D, c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
         } else {
             // last_hidden_state = x_L; pooled = post_layernorm(x_L[:, 0]) (modeling_clip.py:649-656)
             VIT_CHECK_HIP(hipMemcpyAsync(dx, d_hidden, md, hipMemcpyDeviceToDevice, stream));
@@ -385,7 +386,7 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
         VIT_TRY(wgrad(ctx, g, ws, tw, du, g.F, S + y.ln2, g.D, g.M, 0, G + lg.w1, G + lg.b1, stream));
         VIT_TRY(launch_gemm(du, lt.w1T, nullptr, nullptr, dln, g.M, g.D, g.F, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
         VIT_TRY(launch_layernorm_bwd(S + y.xmid, dln, lw.ln2_g, dx, dx2, G + lg.ln2_g, G + lg.ln2_b, g.M, g.D, g.D, g.D, g.D,
-                                     c.layer_norm_eps, stream));
+                                     c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
         // ---- attention branch: x_mid = x + o_proj(attn(qkv(LN1(x))))   (modeling_vit.py:273-277)
         VIT_TRY(wgrad(ctx, g, ws, tw, dx2, g.D, S + y.ctx, g.D, g.M, 0, G + lg.wo, G + lg.bo, stream));
         VIT_TRY(launch_gemm(dx2, lt.woT, nullptr, nullptr, dln, g.M, g.D, g.D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
@@ -396,7 +397,7 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
                       stream));
         VIT_TRY(launch_gemm(dqkv, lt.wqkvT, nullptr, nullptr, dln, g.M, g.D, 3 * g.D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
         VIT_TRY(launch_layernorm_bwd(S + st.x[l], dln, lw.ln1_g, dx2, dx, G + lg.ln1_g, G + lg.ln1_b, g.M, g.D, g.D, g.D, g.D,
-                                     c.layer_norm_eps, stream));
+                                     c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
         return VIT_OK;
     }
 
@@ -405,7 +406,7 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
     const void* dxe = dx;
     if (clip) {
         VIT_TRY(launch_layernorm_bwd(S + st.xe, dx, ctx->pre_g, nullptr, dx2, G + ctx->g_pre_g, G + ctx->g_pre_b, g.M, g.D,
-                                     g.D, g.D, g.D, c.layer_norm_eps, stream));
+                                     g.D, g.D, g.D, c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
         dxe = dx2;
     }
     VIT_TRY(launch_embed_grad(dxe, G + ctx->g_pos, G + ctx->g_cls, batch, g.N, g.D, stream));
