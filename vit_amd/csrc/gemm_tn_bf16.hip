@@ -55,8 +55,16 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
     const int wm = wave >> 2, wn = wave & 3;
     const int q = lane >> 4, i16 = lane & 15;
 
+    // XCD-aware bijective remap (blocks b and b+8 share an XCD): an XCD runs a contiguous range of work
+    // ids = the tiles of one split, which share their token rows of dY and X in that XCD's L2
+    int wid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
     const int tiles = P.tiles_m * P.tiles_n;
-    const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
+    const int split = wid / tiles, tile = wid - split * tiles;
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int t_begin = split * P.tok_per_split;
