@@ -232,6 +232,25 @@ int main(int argc, char** argv) {
             printf("%-9s %-12s median %8.1f us  %7.1f TF   (min %8.1f us)\n", sh.name, vars[v].name, ms[v][rounds / 2] * 1e3,
                    flop / (ms[v][rounds / 2] * 1e-3) / 1e12, ms[v][0] * 1e3);
         }
+        {   // per-workgroup stamps around the second tile (G8_STAMP in the kernel), 100 MHz counter
+            unsigned long long* ds; hipMalloc(&ds, 256 * 8 * 8); hipMemset(ds, 0, 256 * 8 * 8);
+            g8_stamps = ds;
+            for (int w = 0; w < 3; ++w) launch_gemm_bf16_8p(A, W, B, R, C1, sh.M, sh.N, sh.K, sh.epi, nullptr, st);
+            hipStreamSynchronize(st);
+            g8_stamps = nullptr;
+            std::vector<unsigned long long> hs(256 * 8);
+            hipMemcpy(hs.data(), ds, 256 * 8 * 8, hipMemcpyDeviceToHost);
+            double d[5] = {0, 0, 0, 0, 0}; int n = 0;
+            for (int b = 0; b < 256; ++b) {
+                const unsigned long long* q = &hs[b * 8];
+                if (!q[0] || !q[5]) continue;
+                d[0] += (q[1] - q[0]) / 100.0; d[1] += (q[2] - q[1]) / 100.0; d[2] += (q[3] - q[2]) / 100.0;
+                d[3] += (q[4] - q[3]) / 100.0; d[4] += (q[5] - q[4]) / 100.0; ++n;
+            }
+            if (n) printf("%-9s stamps (%d wgs): main loop %.2f us (%d K-tiles), wait vm(4) %.2f, epilogue %.2f, next tile K-tile0 %.2f, K-tile1 %.2f\n",
+                          sh.name, n, d[0] / n, sh.K / 64, d[1] / n, d[2] / n, d[3] / n, d[4] / n);
+            hipFree(ds);
+        }
         hipFree(A); hipFree(W); hipFree(C0); hipFree(C1); hipFree(B); hipFree(R);
         fflush(stdout);
     }

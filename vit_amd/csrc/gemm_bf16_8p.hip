@@ -80,6 +80,7 @@ struct PParams {
     int TMN;     // output tiles per split = ceil(M/256) * NT
     int T;       // total work items = TMN * splits; split s writes the fp32 slab C + s*M*N (OUTM 1)
     int dbg;     // lab only (G8_LAB): bit0 = timing-only run without output stores
+    unsigned long long* stamps;  // lab only: 8 x s_memrealtime per workgroup around its second tile
 };
 
 // EPI: VIT_EPI_* ; for VIT_EPI_DGELU / VIT_EPI_DQUICK_GELU `res` is the pre-activation the
@@ -245,12 +246,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // team 1 runs one barrier behind team 0
 
+#ifdef G8_LAB
+    unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int tcount = 0;
+#define G8_STAMP(i, cond) do { if (P.stamps && (cond)) stp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define G8_STAMP(i, cond) do { } while (0)
+#endif
     for (;;) {
         const int nlt = lt + gx;
         const bool has_next = nlt < cnt;
         next_tile = has_next ? start + nlt : cur_tile;  // no next tile: harmless re-prefetch of this one
+        G8_STAMP(0, tcount == 1);
         ktile(I0{}, I0{}, BT{}, 0);
+        G8_STAMP(4, tcount == 2);
         ktile(I1{}, I0{}, BF{}, 1);
+        G8_STAMP(5, tcount == 2);
         for (int t = 2; t < nk - 2; t += 2) {
             ktile(I0{}, I0{}, BF{}, t);
             ktile(I1{}, I0{}, BF{}, t + 1);
@@ -260,8 +271,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
 
         // Both teams run the epilogue in the same barrier interval: team 0 waits one barrier
         // before it, team 1 one barrier after it (which also restores the stagger).
+        G8_STAMP(1, tcount == 1);
         if (wr == 0) __builtin_amdgcn_s_barrier();
         G8_WAIT_VM(4);  // retire B_h1/A_h1 of the next tile's K-tile 0 before any epilogue traffic
+        G8_STAMP(2, tcount == 1);
         {
             // lane (c = lane&15, g = lane>>4): acc[ha][mi][hb][ni][j] is output row
             // ha*128 + wr*64 + mi*16 + 4g + j, column wc*64 + 4c + (2hb + ni): 8-byte stores, 16 lanes
@@ -347,11 +360,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                         }
                     }
         }
+        G8_STAMP(3, tcount == 1);
+#ifdef G8_LAB
+        ++tcount;
+#endif
         if (wr == 1) __builtin_amdgcn_s_barrier();
         if (!has_next) break;
         lt = nlt;
         cur_tile = next_tile;
     }
+#ifdef G8_LAB
+    if (P.stamps && threadIdx.x == 0)
+        for (int i2 = 0; i2 < 8; ++i2) P.stamps[(size_t)blockIdx.x * 8 + i2] = stp[i2];
+#endif
     G8_WAIT_VM(0);  // the dummy prefetch of the last tile must land before the LDS is released
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance team 1's extra barrier
 }
@@ -381,6 +402,7 @@ bool gemm_bf16_8p_eligible(int M, int N, int K) {
 
 #ifdef G8_LAB
 int g8_dbg = 0;      // lab: bit0 = timing-only build without output stores
+unsigned long long* g8_stamps = nullptr;  // lab: device buffer of 8 stamps per workgroup
 #endif
 int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
                         int epi, const GemmExt* ext, hipStream_t stream) {
@@ -404,6 +426,7 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
     if (splits > 1) P.C = (bf16_t*)ext->slabs;
 #ifdef G8_LAB
     P.dbg = g8_dbg;
+    P.stamps = g8_stamps;
 #endif
     const bool f32out = ext && ext->out_f32;
     const bool pre = P.Cpre != nullptr;
