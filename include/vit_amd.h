@@ -202,7 +202,8 @@ int vit_grad_layer_range(vit_ctx* ctx, int layer, size_t* offset_bytes, size_t* 
  * Allocates; call once after loading, not on the hot path. */
 int vit_train_init(vit_ctx* ctx, void* stream);
 int vit_train_refresh_transposes(vit_ctx* ctx, void* stream);
-/* vit_forward that also fills `stash` (ViTModel.forward MV:356-388 with every intermediate kept). */
+/* vit_forward that also fills `stash` (ViTModel.forward MV:356-388 with every intermediate kept).
+ * Like vit_forward it runs batches of >= 64 images as two halves on two streams. */
 int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
                       void* pooled_out, void* stash, size_t stash_bytes, void* workspace, size_t workspace_bytes,
                       void* stream);

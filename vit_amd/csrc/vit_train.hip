@@ -280,48 +280,70 @@ extern "C" int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel
     const int act_epi = c.hidden_act == VIT_ACT_GELU ? VIT_EPI_GELU : VIT_EPI_QUICK_GELU;
     const int T = VIT_BF16;
 
-    const void* pix = pixels_dev;
-    if (pixel_dtype != T) {
-        VIT_TRY(launch_convert(pixels_dev, pixel_dtype, ws + tw.pix, T,
-                               (int64_t)batch * c.num_channels * c.image_size * c.image_size, stream));
-        pix = ws + tw.pix;
-    }
-    void* x0 = S + (clip ? st.xe : st.x[0]);
-    VIT_TRY(launch_cls_rows(ctx->cls, ctx->pos, x0, batch, g.N, g.D, T, stream));
-    PatchGeom pg{c.num_channels, c.image_size, c.patch_size, c.image_size / c.patch_size, ctx->kreal};
-    VIT_TRY(launch_gemm(pix, ctx->patch_w, ctx->patch_b, nullptr, x0, batch * (g.N - 1), g.D, ctx->kpad, VIT_EPI_BIAS, T,
-                        &pg, ctx->pos, stream));
-    if (clip) VIT_TRY(launch_layernorm(x0, ctx->pre_g, ctx->pre_b, S + st.x[0], g.M, g.D, g.D, g.D, c.layer_norm_eps, T, stream));
+    // One contiguous range of images [b0, b0 + nb) on one stream: every stash tensor is [M, width], so a range
+    // is a row offset into each of them.
+    auto run = [&](int b0, int nb, hipStream_t stream) -> int {
+        const size_t ro = (size_t)b0 * g.N;  // first token row of the range
+        const int Mr = nb * g.N;
+        auto R = [&](size_t off, int width) { return (void*)(S + off + ro * (size_t)width * 2); };
+        const size_t img = (size_t)c.num_channels * c.image_size * c.image_size;
+        const void* pix = (const char*)pixels_dev + (size_t)b0 * img * esize(pixel_dtype);
+        if (pixel_dtype != T) {
+            void* dst = ws + tw.pix + (size_t)b0 * img * 2;
+            VIT_TRY(launch_convert(pix, pixel_dtype, dst, T, (int64_t)nb * img, stream));
+            pix = dst;
+        }
+        void* x0 = R(clip ? st.xe : st.x[0], g.D);
+        VIT_TRY(launch_cls_rows(ctx->cls, ctx->pos, x0, nb, g.N, g.D, T, stream));
+        PatchGeom pg{c.num_channels, c.image_size, c.patch_size, c.image_size / c.patch_size, ctx->kreal};
+        VIT_TRY(launch_gemm(pix, ctx->patch_w, ctx->patch_b, nullptr, x0, nb * (g.N - 1), g.D, ctx->kpad, VIT_EPI_BIAS, T, &pg,
+                            ctx->pos, stream));
+        if (clip)
+            VIT_TRY(launch_layernorm(x0, ctx->pre_g, ctx->pre_b, R(st.x[0], g.D), Mr, g.D, g.D, g.D, c.layer_norm_eps, T, stream));
+        for (int l = 0; l < g.L; ++l) {
+            const LayerW& lw = ctx->layers[l];
+            const Stash::Lay& y = st.lay[l];
+            void* x = R(st.x[l], g.D);
+            VIT_TRY(launch_layernorm(x, lw.ln1_g, lw.ln1_b, R(y.ln1, g.D), Mr, g.D, g.D, g.D, c.layer_norm_eps, T, stream));
+            VIT_TRY(launch_gemm(R(y.ln1, g.D), lw.wqkv, lw.bqkv, nullptr, R(y.qkv, 3 * g.D), Mr, 3 * g.D, g.D, VIT_EPI_BIAS, T,
+                                nullptr, nullptr, stream));
+            float* lse = (float*)(S + y.lse) + (size_t)b0 * g.H * g.N;
+            VIT_TRY(launch_attention(R(y.qkv, 3 * g.D), R(y.ctx, g.D), nb, g.N, g.H, ctx->dh, T, stream, lse));
+            VIT_TRY(launch_gemm(R(y.ctx, g.D), lw.wo, lw.bo, x, R(y.xmid, g.D), Mr, g.D, g.D, VIT_EPI_RESIDUAL, T, nullptr,
+                                nullptr, stream));
+            VIT_TRY(launch_layernorm(R(y.xmid, g.D), lw.ln2_g, lw.ln2_b, R(y.ln2, g.D), Mr, g.D, g.D, g.D, c.layer_norm_eps, T,
+                                     stream));
+            GemmExt ext{R(y.u, g.F), 0, 1, nullptr};
+            VIT_TRY(launch_gemm(R(y.ln2, g.D), lw.w1, lw.b1, nullptr, R(y.h, g.F), Mr, g.F, g.D, act_epi, T, nullptr, nullptr,
+                                stream, &ext));
+            VIT_TRY(launch_gemm(R(y.h, g.F), lw.w2, lw.b2, R(y.xmid, g.D), R(st.x[l + 1], g.D), Mr, g.D, g.F, VIT_EPI_RESIDUAL, T,
+                                nullptr, nullptr, stream));
+        }
+        void* xl = R(st.x[g.L], g.D);
+        void* hid = (char*)hidden_out + ro * g.D * 2;
+        void* pool = pooled_out ? (char*)pooled_out + (size_t)b0 * g.D * 2 : nullptr;
+        if (!clip) {
+            VIT_TRY(launch_layernorm(xl, ctx->fin_g, ctx->fin_b, hid, Mr, g.D, g.D, g.D, c.layer_norm_eps, T, stream));
+        } else {
+            VIT_CHECK_HIP(hipMemcpyAsync(hid, xl, (size_t)Mr * g.D * 2, hipMemcpyDeviceToDevice, stream));
+        }
+        if (pool)
+            VIT_TRY(launch_layernorm(xl, ctx->fin_g, ctx->fin_b, pool, nb, g.D, (int64_t)g.N * g.D, g.D, c.layer_norm_eps, T,
+                                     stream));
+        return VIT_OK;
+    };
 
-    for (int l = 0; l < g.L; ++l) {
-        const LayerW& lw = ctx->layers[l];
-        const Stash::Lay& y = st.lay[l];
-        void* x = S + st.x[l];
-        VIT_TRY(launch_layernorm(x, lw.ln1_g, lw.ln1_b, S + y.ln1, g.M, g.D, g.D, g.D, c.layer_norm_eps, T, stream));
-        VIT_TRY(launch_gemm(S + y.ln1, lw.wqkv, lw.bqkv, nullptr, S + y.qkv, g.M, 3 * g.D, g.D, VIT_EPI_BIAS, T, nullptr,
-                            nullptr, stream));
-        VIT_TRY(launch_attention(S + y.qkv, S + y.ctx, batch, g.N, g.H, ctx->dh, T, stream, (float*)(S + y.lse)));
-        VIT_TRY(launch_gemm(S + y.ctx, lw.wo, lw.bo, x, S + y.xmid, g.M, g.D, g.D, VIT_EPI_RESIDUAL, T, nullptr, nullptr,
-                            stream));
-        VIT_TRY(launch_layernorm(S + y.xmid, lw.ln2_g, lw.ln2_b, S + y.ln2, g.M, g.D, g.D, g.D, c.layer_norm_eps, T, stream));
-        GemmExt ext{S + y.u, 0, 1, nullptr};
-        VIT_TRY(launch_gemm(S + y.ln2, lw.w1, lw.b1, nullptr, S + y.h, g.M, g.F, g.D, act_epi, T, nullptr, nullptr, stream,
-                            &ext));
-        VIT_TRY(launch_gemm(S + y.h, lw.w2, lw.b2, S + y.xmid, S + st.x[l + 1], g.M, g.D, g.F, VIT_EPI_RESIDUAL, T, nullptr,
-                            nullptr, stream));
-    }
-    void* xl = S + st.x[g.L];
-    if (!clip) {
-        VIT_TRY(launch_layernorm(xl, ctx->fin_g, ctx->fin_b, hidden_out, g.M, g.D, g.D, g.D, c.layer_norm_eps, T, stream));
-        if (pooled_out)
-            VIT_TRY(launch_layernorm(xl, ctx->fin_g, ctx->fin_b, pooled_out, batch, g.D, (int64_t)g.N * g.D, g.D,
-                                     c.layer_norm_eps, T, stream));
-    } else {
-        VIT_CHECK_HIP(hipMemcpyAsync(hidden_out, xl, (size_t)g.M * g.D * 2, hipMemcpyDeviceToDevice, stream));
-        if (pooled_out)
-            VIT_TRY(launch_layernorm(xl, ctx->fin_g, ctx->fin_b, pooled_out, batch, g.D, (int64_t)g.N * g.D, g.D,
-                                     c.layer_norm_eps, T, stream));
-    }
+    // as vit_forward: two halves on two streams, so one half's kernels fill the CUs the other half's last
+    // round of GEMM tiles leaves idle (the stash keeps its single-batch layout)
+    const int k = (ctx->nstreams >= 2 && batch >= 64) ? 2 : 1;
+    if (k == 1) return run(0, batch, stream);
+    const int h0 = (batch + 1) / 2;
+    VIT_CHECK_HIP(hipEventRecord(ctx->ev_fork, stream));
+    VIT_CHECK_HIP(hipStreamWaitEvent(ctx->aux_stream[0], ctx->ev_fork, 0));
+    VIT_TRY(run(0, h0, stream));
+    VIT_TRY(run(h0, batch - h0, ctx->aux_stream[0]));
+    VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[0], ctx->aux_stream[0]));
+    VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[0], 0));
     return VIT_OK;
 }
 
