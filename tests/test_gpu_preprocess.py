@@ -203,3 +203,16 @@ def test_image_to_embedding_pipeline():
     px = torch.from_numpy(po.preprocess(img.numpy(), size={"height": 32, "width": 32}))[None]
     hid, pooled = vit_oracle.forward(px, sd, cfg)
     assert rel_err(out.last_hidden_state, hid) < 1e-4
+
+
+def test_plan_cache_is_bounded():
+    from vit_amd.image_processor import ImageProcessor
+    proc = ImageProcessor.vit(16, device="cuda:0")
+    proc.max_plans = 3
+    outs = {}
+    for w in (20, 21, 22, 23, 24, 20):
+        img = synth.synthetic_uint8_image(18, w, 3, seed=9, name=f"c{w}")
+        out = proc(img)["pixel_values"][0].cpu().numpy()
+        want = po.preprocess(img.numpy(), size={"height": 16, "width": 16})
+        assert np.array_equal(out, want)
+        assert len(proc._plans) <= 3

@@ -90,7 +90,8 @@ class ImageProcessor:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype
-        self._plans: Dict[Tuple[int, int, int], _Plan] = {}
+        self._plans: Dict[Tuple[int, int, int], _Plan] = {}  # insertion-ordered: least recently used first
+        self.max_plans = 64  # each plan holds small device tables + a workspace; oldest geometry is dropped
 
     @classmethod
     def vit(cls, image_size: int = 224, **kw) -> "ImageProcessor":
@@ -164,9 +165,14 @@ class ImageProcessor:
             for im in batches:
                 b, h, w, c = im.shape
                 key = (h, w, c)
-                plan = self._plans.get(key)
+                plan = self._plans.pop(key, None)
                 if plan is None:
-                    plan = self._plans[key] = _Plan(self.plan_config(h, w, c), self.device)
+                    plan = _Plan(self.plan_config(h, w, c), self.device)
+                    while len(self._plans) >= self.max_plans:
+                        # the evicted plan may still be in use by queued launches: drain before freeing
+                        torch.cuda.current_stream().synchronize()
+                        self._plans.pop(next(iter(self._plans))).close()
+                self._plans[key] = plan  # most recently used last
                 src = im.to(self.device, non_blocking=True).contiguous()
                 oh, ow = plan.out_hw
                 dst = torch.empty(b, c, oh, ow, dtype=self.dtype, device=self.device)
