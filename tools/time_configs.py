@@ -1,5 +1,5 @@
 """Forward throughput of the other BASELINE.json configurations on one GPU (CLIP-L/14-336 batch 128/8 = 16
-and 128, ViT-H/14-448 batch 32), synthetic weights. Usage: python tools/time_configs.py"""
+and 128, ViT-H/14-448 batch 32), synthetic weights. Usage: python tools/time_configs.py [name[:batch] ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,8 +8,11 @@ from vit_amd.config import ViTConfig
 from vit_amd.encoder import ViTEncoder
 
 PEAK = 2.5e15
+WANT = sys.argv[1:]
 for name, cfg, batch in (("vit_b16_224", ViTConfig.vit_b16_224(), 256), ("clip_l14_336", ViTConfig.clip_l14_336(), 128),
                          ("clip_l14_336", ViTConfig.clip_l14_336(), 16), ("vit_h14_448", ViTConfig.vit_h14_448(), 32)):
+    if WANT and name not in WANT and f"{name}:{batch}" not in WANT:
+        continue
     sd = synth.synthetic_state_dict(cfg, seed=0, device="cuda")
     enc = ViTEncoder(cfg, dtype=torch.bfloat16, device="cuda:0")
     enc.load_state_dict(sd)

@@ -25,6 +25,10 @@
 #include "vit_common.h"
 #include <math.h>
 
+#ifndef ATTN_VAR
+#define ATTN_VAR 0  // lab only (tools/attn_lab.hip): timing-only variants, results garbage
+#endif
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -60,6 +64,13 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
 }
 
 typedef int int4v __attribute__((ext_vector_type(4)));
+
+// max over the two lane halves (lane l and lane l ^ 32) without the LDS round trip of a shuffle
+__device__ __forceinline__ float max_across_halves(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+}
 
 template <bool LSE>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_dh64_kernel(
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             // ---- counted wait: everything up to this wave's piece of the current tile has landed.
             // Younger operations that may stay in flight: R-2 DMAs; while p <= R-2 also the previous
             // item's ST stores (if this wave had queries in it) and, from p = 1, the NQ loads of the Q prefetch.
+#if ATTN_VAR != 4 && ATTN_VAR != 5
             {
                 const bool inwin = p <= R - 2;
                 const bool stin = inwin && prev_active;
@@ -187,6 +199,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
             }
             asm volatile("s_barrier" ::: "memory");  // every wave's piece landed; the previous tile's slot is free
+#endif
             if (p == 0) {
                 // this item's Q fragments (DMA issued one item ago, older than the tile just waited
                 // for) -> registers; then the slot is free for the next item's Q (clamped to the last
@@ -199,7 +212,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 const int nbh = item_bh(jn, &nqb);
                 dma_q(item_rsrc(src.q, nbh), (nqb * NW + wave) * 32);
             }
+#if ATTN_VAR != 5
             dma_next(pslot);
+#endif
             pslot = pslot + 1 == R ? 0 : pslot + 1;
 
             if (active) {
@@ -209,11 +224,33 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 f32x16 s;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#if ATTN_VAR == 3
+                for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(s[e]));
+#else
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8 kf = *(const bf16x8*)(Kb + kro[ks]);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
                 }
+#endif
+#if ATTN_VAR != 2
+                // V^T fragments of both key halves by ds_read_b64_tr_b16, issued now (the tile landed before
+                // the barrier) and waited for just before the PV products, so their latency hides behind
+                // the softmax. Inline asm: through the builtin the compiler orders every such read behind
+                // vmcnt(0) (it may alias a DMA target), which would drain the ring it reads from.
+                short4v vl[8];
+                {
+                    const unsigned va0 = kb_lds + vro[0], va1 = kb_lds + vro[1];
+                    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+                                 "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+                                 "ds_read_b64_tr_b16 %4, %8 offset:2048\n\tds_read_b64_tr_b16 %5, %8 offset:3072\n\t"
+                                 "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072"
+                                 : "=&v"(vl[0]), "=&v"(vl[1]), "=&v"(vl[2]), "=&v"(vl[3]), "=&v"(vl[4]), "=&v"(vl[5]),
+                                   "=&v"(vl[6]), "=&v"(vl[7])
+                                 : "v"(va0), "v"(va1)
+                                 : "memory");
+                }
+#endif
                 const int key0 = p * 32;
                 if (key0 + 32 > N) {  // wave-uniform: only the last tile of the sequence
 #pragma unroll
@@ -222,10 +259,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         if (key >= N) s[e] = -INFINITY;
                     }
                 }
+#if ATTN_VAR != 1
                 float mx = s[0];
 #pragma unroll
                 for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = max_across_halves(mx);
                 const float m_new = fmaxf(m_run, mx * scale_log2e);
                 // rescale O / l only when some query of the wave saw a larger score (exact, wave-uniform)
                 if (__any(m_new > m_run)) {
@@ -244,26 +282,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     psum += s[e];
                 }
                 l_run += psum;
+#endif
                 // ---- O^T += V^T P^T ----
+#if ATTN_VAR == 2
 #pragma unroll
-                // V^T fragments by ds_read_b64_tr_b16, issued as inline asm: through the builtin the
-                // compiler orders every such read behind vmcnt(0) (it may alias a DMA target), which
-                // would drain the ring it reads from.
+                for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(s[e]));
+#else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(vl[0]), "+v"(vl[1]), "+v"(vl[2]), "+v"(vl[3]), "+v"(vl[4]), "+v"(vl[5]), "+v"(vl[6]), "+v"(vl[7])::"memory");
+#pragma unroll
                 for (int sk = 0; sk < 2; ++sk) {
                     const bf16x8 pb = pack8(s, sk);
-                    const unsigned va0 = kb_lds + vro[0] + sk * 2048, va1 = kb_lds + vro[1] + sk * 2048;
-                    short4v l0, h0, l1, h1;
-                    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:1024\n\t"
-                                 "ds_read_b64_tr_b16 %2, %5\n\tds_read_b64_tr_b16 %3, %5 offset:1024\n\t"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1)
-                                 : "v"(va0), "v"(va1)
-                                 : "memory");
-                    const short8v b0 = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const short8v b1 = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const short8v b0 = __builtin_shufflevector(vl[4 * sk + 0], vl[4 * sk + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const short8v b1 = __builtin_shufflevector(vl[4 * sk + 2], vl[4 * sk + 3], 0, 1, 2, 3, 4, 5, 6, 7);
                     o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), pb, o[0], 0, 0, 0);
                     o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), pb, o[1], 0, 0, 0);
                 }
+#endif
             }
             slot = slot + 1 == R ? 0 : slot + 1;
         }
