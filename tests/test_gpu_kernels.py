@@ -176,7 +176,10 @@ def test_attention_uniform_scores_average_values():
 
 # ------------------------------------------------------------------ patch embedding
 @pytest.mark.parametrize("b,c,img,p,d", [(3, 3, 32, 8, 64), (2, 3, 42, 14, 160), (2, 3, 224, 16, 128),
-                                          (1, 3, 336, 14, 64), (2, 1, 30, 5, 32), (5, 3, 224, 16, 768)])
+                                          (1, 3, 336, 14, 64), (2, 1, 30, 5, 32), (5, 3, 224, 16, 768),
+                                          # big enough for the persistent kernel's pixel loader (bf16): ragged last
+                                          # row tile / image seams inside tiles, ragged last column tile, P = 32
+                                          (30, 3, 224, 16, 768), (28, 3, 224, 16, 776), (86, 3, 256, 32, 768)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_bias", [True, False])
 def test_patch_embed(b, c, img, p, d, dtype, with_bias):

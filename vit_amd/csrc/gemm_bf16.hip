@@ -323,6 +323,9 @@ int pick_bn(int M, int N) {
 bool gemm_bf16_8p_eligible(int M, int N, int K);
 int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
                         int epi, const GemmExt* ext, hipStream_t stream);
+bool gemm_bf16_8p_patch_eligible(int M, int N, const PatchGeom* g);
+int launch_gemm_bf16_8p_patch(const void* pixels, const void* W, const float* bias, const float* pos, void* C, int M, int N,
+                              const PatchGeom* g, hipStream_t stream);
 
 // generic tile kernel of this file (any K % 8 == 0, patch loaders); also the lab's baseline
 int launch_gemm_bf16_generic(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N,
@@ -340,6 +343,10 @@ int launch_gemm_bf16(const void* A, const void* W, const float* bias, const void
     const int splits = (ext && ext->split_k > 1) ? ext->split_k : 1;
     if (patch == nullptr && gemm_bf16_8p_eligible(M, N, K) && (long)M * N * splits >= 64L * 256 * 256)
         return launch_gemm_bf16_8p(A, W, bias, res, C, M, N, K, epi, ext, stream);
+    // patch embedding with whole-pixel-row K-tiles (P = 16, 32): persistent kernel with the pixel loader
+    if (patch != nullptr && ext == nullptr && epi == VIT_EPI_BIAS && pos != nullptr && K == patch->kreal &&
+        gemm_bf16_8p_patch_eligible(M, N, patch) && (long)M * N >= 64L * 256 * 256)
+        return launch_gemm_bf16_8p_patch(A, W, bias, pos, C, M, N, patch, stream);
     VIT_REQUIRE(splits == 1, "gemm: split-K requested for a shape the persistent kernel does not take");
     return launch_gemm_bf16_generic(A, W, bias, res, C, M, N, K, epi, patch, pos, stream, ext);
 }

@@ -1,8 +1,12 @@
 // bf16 MFMA GEMM, persistent deep-pipelined kernel for the encoder's big Linear layers:
 //     C[M,N] = epi(A[M,K] * W[N,K]^T + bias (+ residual)),   K % 128 == 0, K >= 256
 // (q/k/v packed projection modeling_vit.py:216-218, o_proj + residual :236,:277, fc1 + GELU
-// :250-251, fc2 + residual :252,:284). Shapes it does not take (K tails, the im2col-free
-// patch loader) stay on gemm_bf16.hip.
+// :250-251, fc2 + residual :252,:284), and -- EPI_PATCH -- the patch embedding (Conv2d with
+// kernel = stride = P, modeling_vit.py:62-69) for patch sizes whose K-tiles are whole pixel rows
+// of one channel (P = 16, 32): the A operand is DMA'd straight from the pixel tensor (per-lane
+// offset of the patch row + a wave-uniform offset per K-tile), the epilogue moves rows past each
+// image's CLS slot and adds the position table (:129-161). Shapes it does not take (K tails, other
+// patch sizes) stay on gemm_bf16.hip.
 //
 // gfx950 design (DESIGN.md "GEMM"):
 //  * Persistent: one 512-thread workgroup per CU walks a list of 256 x 256 output tiles. Blocks
@@ -79,11 +83,19 @@ struct PParams {
     int NT;      // tiles along N
     int TMN;     // output tiles per split = ceil(M/256) * NT
     int T;       // total work items = TMN * splits; split s writes the fp32 slab C + s*M*N (OUTM 1)
+    // EPI_PATCH only: A is the pixel tensor [B, C, image, image]; GEMM row g = b * np + py * grid + px
+    const float* pos;        // position table fp32 [np + 1, N]
+    int np, grid, patch, image;
+    unsigned img_bytes;      // C * image * image * 2
+    int a_kshift, a_kmask;   // K-tile kt starts at byte (kt >> a_kshift) * a_chs + (kt & a_kmask) * a_kts of a patch
+    unsigned a_chs, a_kts;
     int dbg;     // lab only (G8_LAB): bit0 = timing-only run without output stores
     unsigned long long* stamps;  // lab only: 8 x s_memrealtime per workgroup around its second tile
 };
 
-// EPI: VIT_EPI_* ; for VIT_EPI_DGELU / VIT_EPI_DQUICK_GELU `res` is the pre-activation the
+constexpr int EPI_PATCH = 100;  // internal: bias + position add + row remap past the CLS slot, A from pixels
+
+// EPI: VIT_EPI_* or EPI_PATCH; for VIT_EPI_DGELU / VIT_EPI_DQUICK_GELU `res` is the pre-activation the
 // gradient is multiplied with. OUTM: 0 = bf16 C, 1 = fp32 C (weight gradients), 2 = bf16 C plus
 // the pre-activation in Cpre.
 template <int EPI, int OUTM>
@@ -122,7 +134,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                 const int sw = (r >> 1) & 7;
                 int ar = h * 128 + r;
                 if (m0 + ar > P.M - 1) ar = P.M - 1 - m0;
-                a_of[h][j] = ((unsigned)ar * (unsigned)P.lda + (unsigned)((p ^ sw) << 3)) * 2u;
+                if constexpr (EPI == EPI_PATCH) {
+                    // patch row: offset of its first pixel from the tile's first image, plus this lane's
+                    // 16-byte chunk inside the K-tile (chunk c = 8 pixels: row (8c / P), column (8c % P))
+                    const int g = m0 + ar, b = g / P.np, rem = g - b * P.np;
+                    const int py = rem / P.grid, px = rem - py * P.grid;
+                    const int c8 = (p ^ sw) << 3;
+                    const unsigned pix = (unsigned)((py * P.patch + c8 / P.patch) * P.image + px * P.patch + c8 % P.patch);
+                    a_of[h][j] = (unsigned)(b - m0 / P.np) * P.img_bytes + pix * 2u;
+                } else {
+                    a_of[h][j] = ((unsigned)ar * (unsigned)P.lda + (unsigned)((p ^ sw) << 3)) * 2u;
+                }
                 const int rr = r & 31;
                 // B half h, LDS row (wc*32 + ni*16 + c) holds tile column wc*64 + 4c + (2h + ni): the four
                 // 16-column MFMA fragments of a wave interleave to 4 consecutive columns per lane
@@ -133,14 +155,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         // num_records spans the (clamped) 256 rows of the tile; offsets never exceed it
         const unsigned span = (unsigned)BM * (unsigned)P.lda * 2u;
         const size_t koff = (size_t)sp * P.K;  // this split's first k
-        Ar = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * P.lda + koff), 0, span, 0x00020000);
+        if constexpr (EPI == EPI_PATCH) {
+            // based at the tile's first image; the (clamped) rows of a tile lie in at most 256 / np + 2 images
+            const int b0 = m0 / P.np, bl = (P.M - 1) / P.np;
+            const int nimg = (bl - b0 + 1 < 256 / P.np + 2) ? bl - b0 + 1 : 256 / P.np + 2;
+            Ar = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)b0 * P.img_bytes), 0,
+                                                   (unsigned)nimg * P.img_bytes, 0x00020000);
+        } else {
+            Ar = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * P.lda + koff), 0, span, 0x00020000);
+        }
         Wr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * P.lda + koff), 0, span, 0x00020000);
     };
     unsigned char* const dma_base = smem + wave * 1024;
     auto stage_a = [&](int h, int buf, int kt) {
         unsigned char* d = dma_base + buf * BUF_BYTES + (h ? OFF_A1 : OFF_A0);
-        bufdma16(Ar, a_of[h][0], kt * (BK * 2), d);
-        bufdma16(Ar, a_of[h][1], kt * (BK * 2), d + 8192);
+        int ko = kt * (BK * 2);
+        if constexpr (EPI == EPI_PATCH) ko = (int)((unsigned)(kt >> P.a_kshift) * P.a_chs + (unsigned)(kt & P.a_kmask) * P.a_kts);
+        bufdma16(Ar, a_of[h][0], ko, d);
+        bufdma16(Ar, a_of[h][1], ko, d + 8192);
     };
     auto stage_b = [&](int h, int buf, int kt) {
         unsigned char* d = dma_base + buf * BUF_BYTES + (h ? OFF_B1 : OFF_B0);
@@ -288,6 +320,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             const int nb = n0 + wc * 64 + 4 * i;
             const bool col_ok = nb < P.N;  // N % 8 == 0: 4 columns all in or all out
             const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
+            if constexpr (EPI == EPI_PATCH) {
+                // GEMM row g = b * np + patch goes to output row g + b + 1 (one CLS slot per image) and gets
+                // position row 1 + patch. The tile's rows lie in at most 5 images (np >= 64, host check):
+                // b - b0 = number of image starts e1, e1 + np, ... at or below the local row.
+                const int b0 = m0 / P.np;
+                const int e1 = (b0 + 1) * P.np - m0;
+                const unsigned out_rows = (unsigned)(rows_here + (m0 + rows_here - 1) / P.np - b0);
+                const __amdgpu_buffer_rsrc_t Cr = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(P.C + (size_t)(m0 + b0 + 1) * P.N), 0, (P.dbg & 1) ? 0u : out_rows * (unsigned)P.N * 2u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t Qr = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)P.pos, 0, (unsigned)(P.np + 1) * (unsigned)P.N * 4u, 0x00020000);
+                float bias[4] = {0.f, 0.f, 0.f, 0.f};
+                if (P.bias != nullptr && col_ok) {
+                    const float4 b4 = *(const float4*)(P.bias + nb);
+                    bias[0] = b4.x; bias[1] = b4.y; bias[2] = b4.z; bias[3] = b4.w;
+                }
+#pragma unroll
+                for (int hm = 0; hm < 4; ++hm) {  // 64 of the lane's rows in 4 batches of 16 (ha = hm >> 1, mi = 2 (hm & 1) + ...)
+                    const int ha = hm >> 1;
+                    u32x4 pp[8];        // position rows of this batch, fetched up front into the dead fragment registers
+                    unsigned vo[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const int lr = ha * 128 + wr * 64 + ((hm & 1) * 2 + (s >> 2)) * 16 + 4 * q + (s & 3);
+                        const int extra = (lr >= e1) + (lr >= e1 + P.np) + (lr >= e1 + 2 * P.np) + (lr >= e1 + 3 * P.np);
+                        const int pr = m0 + lr - (b0 + extra) * P.np + 1;
+                        vo[s] = col_ok ? (unsigned)((lr + extra) * P.N + nb) * 2u : 0x80000000u;
+                        pp[s] = __builtin_amdgcn_raw_buffer_load_b128(Qr, col_ok ? (int)((unsigned)(pr * P.N + nb) * 4u) : (int)0x80000000u, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const int mi = (hm & 1) * 2 + (s >> 2), j = s & 3;
+                        // (bit_cast of the whole vector: __builtin_bit_cast on a vector ELEMENT reads element 0)
+                        const f32x4 pf = __builtin_bit_cast(f32x4, pp[s]);
+                        bf16x4 ov;
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni)
+                                ov[hb * 2 + ni] = (bf16_t)(acc[ha][mi][hb][ni][j] + bias[hb * 2 + ni] + pf[hb * 2 + ni]);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)vo[s], 0, 0);
+                    }
+                }
+            } else {
             constexpr bool USES_RES = (EPI == VIT_EPI_RESIDUAL || EPI == VIT_EPI_DGELU || EPI == VIT_EPI_DQUICK_GELU);
             constexpr unsigned OES = (OUTM == 1) ? 4u : 2u;  // output element size
             const unsigned span = (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * 2u;
@@ -359,6 +435,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, 0);
                         }
                     }
+            }  // !EPI_PATCH
         }
         G8_STAMP(3, tcount == 1);
 #ifdef G8_LAB
@@ -398,6 +475,15 @@ int launch_reduce_slabs(const float* slabs, float* out, int splits, int64_t n, h
 // true when the 8-phase kernel takes this problem
 bool gemm_bf16_8p_eligible(int M, int N, int K) {
     return K % 128 == 0 && K >= 256 && N % 8 == 0 && M >= 1 && (size_t)256 * K * 2 < ((size_t)1 << 31);  // K here is the full row pitch
+}
+
+// Patch sizes the persistent kernel's A loader takes: a 64-element K-tile must be whole pixel rows of one
+// channel (P divides 64, P*P a multiple of 64 -> P = 8, 16, 32, 64), and K = C*P*P a legal K.
+bool gemm_bf16_8p_patch_eligible(int M, int N, const PatchGeom* g) {
+    const int P = g->patch, K = g->channels * P * P;
+    return P >= 8 && 64 % P == 0 && (P * P) % 64 == 0 && g->image % 8 == 0 && g->image == g->grid * P && g->kreal == K &&
+           g->grid * g->grid >= 64 && M % (g->grid * g->grid) == 0 && gemm_bf16_8p_eligible(M, N, K) &&
+           (size_t)g->channels * g->image * g->image * 2 * 7 < ((size_t)1 << 32) && (size_t)(g->grid * g->grid + 1) * N * 4 < ((size_t)1 << 32);
 }
 
 #ifdef G8_LAB
@@ -447,4 +533,37 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
         case VIT_EPI_DQUICK_GELU: return g8::launch_persist<VIT_EPI_DQUICK_GELU, 0>(P, ncu, stream);
     }
     return vit_set_error(VIT_E_INVALID, "gemm8p: unknown epilogue %d", epi);
+}
+
+// Patch embedding on the persistent kernel: pixels bf16 [B, C, image, image] -> C rows b*(np+1) + 1 + patch
+// (the CLS rows are written by the caller), + bias + position rows 1..np.
+int launch_gemm_bf16_8p_patch(const void* pixels, const void* W, const float* bias, const float* pos, void* C, int M, int N,
+                              const PatchGeom* g, hipStream_t stream) {
+    VIT_REQUIRE(gemm_bf16_8p_patch_eligible(M, N, g), "gemm8p: patch geometry not eligible");
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        VIT_CHECK_HIP(hipGetDevice(&dev));
+        VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int P = g->patch, K = g->channels * P * P;
+    g8::PParams q{};
+    q.A = (const bf16_t*)pixels; q.W = (const bf16_t*)W; q.bias = bias; q.C = (bf16_t*)C; q.pos = pos;
+    q.M = M; q.N = N; q.K = K; q.lda = K;
+    q.NT = ceil_div(N, g8::BN);
+    q.TMN = ceil_div(M, g8::BM) * q.NT;
+    q.T = q.TMN;
+    q.np = g->grid * g->grid; q.grid = g->grid; q.patch = P; q.image = g->image;
+    q.img_bytes = (unsigned)g->channels * g->image * g->image * 2u;
+    const int kpc = P * P / 64;  // K-tiles per channel: a power of two for P = 8..64
+    int sh = 0;
+    while ((1 << sh) < kpc) ++sh;
+    q.a_kshift = sh; q.a_kmask = kpc - 1;
+    q.a_chs = (unsigned)g->image * g->image * 2u;          // next channel
+    q.a_kts = (unsigned)(64 / P) * g->image * 2u;          // next 64 / P pixel rows
+#ifdef G8_LAB
+    q.dbg = g8_dbg;
+    q.stamps = g8_stamps;
+#endif
+    return g8::launch_persist<g8::EPI_PATCH, 0>(q, ncu, stream);
 }
