@@ -94,6 +94,10 @@ def test_full_batch_properties_vit_b16_bf16():
     assert torch.equal(out_p.last_hidden_state, out.last_hidden_state[perm])
     out_s = enc(px[100:108])
     assert torch.equal(out_s.last_hidden_state, out.last_hidden_state[100:108])
+    # 4 images: every GEMM of the layer is on the generic tile kernel now (the persistent kernel takes the big
+    # ones) -- both kernels give the same bits, folded LayerNorm and GELU epilogues included
+    out_t = enc(px[200:204])
+    assert torch.equal(out_t.last_hidden_state, out.last_hidden_state[200:204])
     sd = vit_oracle.quantize_state_dict_bf16(synth.synthetic_state_dict(cfg, seed=0))
     idx = [0, 101, 255]
     _, ref = vit_oracle.forward(px[idx].float().cpu(), sd, cfg)
@@ -206,3 +210,44 @@ def test_forward_under_graph_capture():
     torch.cuda.synchronize()
     assert torch.equal(out.last_hidden_state, want.last_hidden_state)
     assert torch.equal(out.pooler_output, want.pooler_output)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["vit", "clip"])
+def test_folded_layernorm_matches_unfolded_and_oracle(monkeypatch, variant):
+    """Big enough batches fold LayerNorm into the QKV / fc1 GEMMs (vit_capi.hip refresh_folds: rstd * (x Wg^T) -
+    mean * rstd * c + d in the epilogue, VIT_AMD_FUSE_LN=0 turns it off). Same function, different rounding
+    points: both paths must sit equally close to the fp32 oracle (non-trivial gamma / beta), and the folded
+    copies must follow a weight reload."""
+    kw = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512)
+    cfg = ViTConfig(**kw) if variant == "vit" else ViTConfig(variant="clip", hidden_act="quick_gelu", layer_norm_eps=1e-5, **kw)
+    batch = 44  # 44 * 197 rows: QKV and fc1 both go to the persistent kernel
+
+    def weights(seed):
+        sd = synth.synthetic_state_dict(cfg, seed=seed)
+        g = torch.Generator().manual_seed(100 + seed)
+        for k in sd:
+            if "norm" in k and k.endswith("weight"):
+                sd[k] = 1.0 + 0.3 * torch.randn(sd[k].shape, generator=g)
+            elif "norm" in k and k.endswith("bias"):
+                sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+        return vit_oracle.quantize_state_dict_bf16(sd)
+
+    px = synth.synthetic_images(cfg, batch, seed=1).to(torch.bfloat16)
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("VIT_AMD_FUSE_LN", fuse)
+        enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
+        for seed in (0, 1):  # the second load must refresh the folded copies
+            sd = weights(seed)
+            enc.load_state_dict(sd)
+            outs[(fuse, seed)] = enc(px).last_hidden_state.float().cpu()
+        enc.close()
+    for seed in (0, 1):
+        ref = vit_oracle.forward(px.float(), weights(seed), cfg)[0]
+        e_f, e_u = rel_err(outs[("1", seed)], ref), rel_err(outs[("0", seed)], ref)
+        print(f"{variant} seed {seed}: folded rel err {e_f:.5f}, unfolded {e_u:.5f}")
+        assert e_f < max(1.3 * e_u, 2e-3) and e_f < 2e-2
+        assert min_row_cosine(outs[("1", seed)], ref) >= 0.999
+        assert not torch.equal(outs[("1", seed)], outs[("0", seed)])  # the folded path really ran
+    assert rel_err(outs[("1", 0)], outs[("1", 1)]) > 0.1  # different weights, different outputs

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import vit_oracle
-from tests.helpers import cosine, load_golden, min_row_cosine
+from tests.helpers import cosine, load_golden, min_row_cosine, rel_err
 from vit_amd import synth
 from vit_amd.encoder import ViTEncoder
 from vit_amd.trainer import ViTTrainer
@@ -40,8 +40,12 @@ def test_gradients_match_autograd(name):
     out = tr.forward(px)
     assert min_row_cosine(out.pooler_output, ref_p) >= 0.999
     assert min_row_cosine(out.last_hidden_state, ref_h) >= 0.998
-    inf = enc(px)  # the stashing forward is the same function as the inference forward
-    assert torch.equal(inf.last_hidden_state, out.last_hidden_state)
+    # the stashing forward is the same function as the inference forward; it materialises the LayerNorm outputs
+    # (the weight gradients need them) where the inference forward folds LayerNorm into the next GEMM, so the
+    # two differ by bf16 rounding points only
+    inf = enc(px)
+    assert rel_err(inf.last_hidden_state, out.last_hidden_state) < 2e-2
+    assert min_row_cosine(inf.last_hidden_state, out.last_hidden_state.float().cpu()) >= 0.9995
     tr.backward(w_h, w_p)
     torch.cuda.synchronize()
     worst = (1.0, "")

@@ -45,6 +45,8 @@ struct GemmParams {
     int M, N, K;
     int NT;  // tiles along N
     PatchGeom pg;
+    const float* ln_stats;  // LNF: [M][2] = (mean * rstd, rstd) of the un-normalised A rows
+    const float* ln_c;      // LNF: [N] column sums of the gamma-folded weight
 };
 
 template <int BN>
@@ -149,7 +151,9 @@ struct Stager {
     }
 };
 
-template <int BN, int AMODE, int EPI>
+// LNF: LayerNorm folded in (GemmExt::ln_stats): value = rstd * acc - (mean * rstd) * c + bias, the same
+// fmaf chain as the persistent kernel's epilogue so that both kernels give the same bits.
+template <int BN, int AMODE, int EPI, bool LNF = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const GemmParams P) {
     using G = Geo<BN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -218,16 +222,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const GemmParams
 #pragma unroll
     for (int e = 0; e < 16; ++e) bias[e] = (P.bias != nullptr && nb + e < P.N) ? P.bias[nb + e] : 0.f;
 
+    float lnc[16];
+    if constexpr (LNF) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lnc[e] = (nb + e < P.N) ? P.ln_c[nb + e] : 0.f;
+    }
     const int np = (EPI == EPI_PATCH) ? P.pg.grid * P.pg.grid : 1;
 #pragma unroll
     for (int a = 0; a < G::MI; ++a) {
         const int m = m0 + wm * G::WM + a * 16 + i;
         if (m >= P.M) continue;
         float v[16];
+        if constexpr (LNF) {
+            const float2 st = *(const float2*)(P.ln_stats + (size_t)m * 2);
 #pragma unroll
-        for (int b = 0; b < G::NI; ++b)
+            for (int b = 0; b < G::NI; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[b * 4 + j] = acc[a][b][j] + bias[b * 4 + j];
+                for (int j = 0; j < 4; ++j)
+                    v[b * 4 + j] = fmaf(st.y, acc[a][b][j], fmaf(-st.x, lnc[b * 4 + j], bias[b * 4 + j]));
+        } else {
+#pragma unroll
+            for (int b = 0; b < G::NI; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[b * 4 + j] = acc[a][b][j] + bias[b * 4 + j];
+        }
         size_t orow = (size_t)m;
         if constexpr (EPI == EPI_PATCH) {
             const int bimg = m / np, pr = m - bimg * np + 1;  // token index inside the image (CLS = 0)
@@ -273,10 +291,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const GemmParams
     }
 }
 
-template <int BN, int AMODE, int EPI>
+template <int BN, int AMODE, int EPI, bool LNF = false>
 int launch_one(const GemmParams& P, hipStream_t stream) {
     using G = Geo<BN>;
-    auto kern = gemm_bf16_kernel<BN, AMODE, EPI>;
+    auto kern = gemm_bf16_kernel<BN, AMODE, EPI, LNF>;
     static bool attr_set = false;  // per instantiation; the attribute is idempotent
     if (!attr_set) {
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
@@ -294,6 +312,14 @@ int dispatch_epi(const GemmParams& P, int epi, hipStream_t stream) {
     if constexpr (AMODE != A_DENSE) {
         return launch_one<BN, AMODE, EPI_PATCH>(P, stream);
     } else {
+        if (P.ln_stats) {
+            switch (epi) {
+                case VIT_EPI_BIAS: return launch_one<BN, AMODE, VIT_EPI_BIAS, true>(P, stream);
+                case VIT_EPI_GELU: return launch_one<BN, AMODE, VIT_EPI_GELU, true>(P, stream);
+                case VIT_EPI_QUICK_GELU: return launch_one<BN, AMODE, VIT_EPI_QUICK_GELU, true>(P, stream);
+            }
+            return vit_set_error(VIT_E_INVALID, "gemm: folded LayerNorm with epilogue %d", epi);
+        }
         switch (epi) {
             case VIT_EPI_BIAS: return launch_one<BN, AMODE, VIT_EPI_BIAS>(P, stream);
             case VIT_EPI_GELU: return launch_one<BN, AMODE, VIT_EPI_GELU>(P, stream);
@@ -360,6 +386,10 @@ int launch_gemm_bf16_generic(const void* A, const void* W, const float* bias, co
     P.Cpre = ext ? (bf16_t*)ext->c_pre : nullptr;
     P.out_f32 = ext ? ext->out_f32 : 0;
     VIT_REQUIRE(!P.out_f32 || (epi == VIT_EPI_BIAS && !patch), "gemm: fp32 output only with the plain epilogue");
+    if (ext && ext->ln_stats) {
+        VIT_REQUIRE(ext->ln_colsum != nullptr && !patch && !P.out_f32 && !P.Cpre, "gemm: folded LayerNorm takes the plain bf16 epilogues only");
+        P.ln_stats = ext->ln_stats; P.ln_c = ext->ln_colsum;
+    }
     const int bn = pick_bn(M, N);
     P.NT = ceil_div(N, bn);
     if (patch) {

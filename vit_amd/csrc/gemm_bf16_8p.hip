@@ -83,6 +83,9 @@ struct PParams {
     int NT;      // tiles along N
     int TMN;     // output tiles per split = ceil(M/256) * NT
     int T;       // total work items = TMN * splits; split s writes the fp32 slab C + s*M*N (OUTM 1)
+    // LNF (template flag): LayerNorm folded in -- epilogue value = rstd * acc - (mean * rstd) * ln_c + bias
+    const float* ln_stats;   // [M][2] = (mean * rstd, rstd)
+    const float* ln_c;       // [N]
     // EPI_PATCH only: A is the pixel tensor [B, C, image, image]; GEMM row g = b * np + py * grid + px
     const float* pos;        // position table fp32 [np + 1, N]
     int np, grid, patch, image;
@@ -98,7 +101,7 @@ constexpr int EPI_PATCH = 100;  // internal: bias + position add + row remap pas
 // EPI: VIT_EPI_* or EPI_PATCH; for VIT_EPI_DGELU / VIT_EPI_DQUICK_GELU `res` is the pre-activation the
 // gradient is multiplied with. OUTM: 0 = bf16 C, 1 = fp32 C (weight gradients), 2 = bf16 C plus
 // the pre-activation in Cpre.
-template <int EPI, int OUTM>
+template <int EPI, int OUTM, bool LNF = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     // 2: K-tile nk-1 (all stages belong to the next tile). FIRST: K-tile 0 of a tile (its
     // B_h1/A_h1 were retired before the loop / at the start of the previous epilogue).
     int next_tile = 0;
+    __amdgpu_buffer_rsrc_t Sr = Ar;  // LNF: this tile's rows of ln_stats (rows >= M read as 0)
     auto ktile = [&](auto BUFC, auto MODEC, auto FIRSTC, int t) {
         constexpr int BUF = decltype(BUFC)::value, MODE = decltype(MODEC)::value;
         constexpr bool FIRST = decltype(FIRSTC)::value;
@@ -243,6 +247,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         read_a(BUF, 0);
         stage_b(1, BUF ^ 1, MODE == 2 ? 0 : t + 1);
         if constexpr (!FIRST) G8_WAIT_VM(6);
+        // LNF, last K-tile of a tile: this tile's 256 x (mean * rstd, rstd) go to LDS behind the ring, one 4-byte
+        // DMA per lane (wave w brings dwords 64w..64w+63). Older than the six half-tile stages that follow, so the
+        // vmcnt(8) of ph4 retires it, two barriers before the epilogue reads it.
+        if constexpr (LNF && MODE == 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Sr, LDS_PTR(smem + LDS_BYTES + wave * 256), 4, lane * 4, wave * 256, 0, 0);
         G8P_SECTION(0, 0, Z{});
         // ph2: (A0,B1)
         read_b(BUF, 1);
@@ -289,6 +298,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         const int nlt = lt + gx;
         const bool has_next = nlt < cnt;
         next_tile = has_next ? start + nlt : cur_tile;  // no next tile: harmless re-prefetch of this one
+        if constexpr (LNF) {
+            const int t2 = cur_tile % P.TMN, m0 = (t2 / P.NT) * BM;
+            const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
+            Sr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.ln_stats + (size_t)m0 * 2), 0, (unsigned)rows_here * 8u, 0x00020000);
+        }
         G8_STAMP(0, tcount == 1);
         ktile(I0{}, I0{}, BT{}, 0);
         G8_STAMP(4, tcount == 2);
@@ -381,6 +395,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                 const float4 b0 = *(const float4*)(P.bias + nb);
                 bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
             }
+            // LayerNorm folded in: the tile's (mean * rstd, rstd) are in LDS behind the ring (DMA of the last K-tile);
+            // a lane's rows come in runs of four (32 bytes), and the column sums of the folded weight
+            f32x4 lst[LNF ? 16 : 1];
+            float lnc[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (LNF) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int lr = (s >> 3) * 128 + wr * 64 + ((s >> 1) & 3) * 16 + 4 * q + (s & 1) * 2;
+                    lst[s] = *(const f32x4*)(smem + LDS_BYTES + lr * 8);
+                }
+                if (col_ok) {
+                    const float4 c4 = *(const float4*)(P.ln_c + nb);
+                    lnc[0] = c4.x; lnc[1] = c4.y; lnc[2] = c4.z; lnc[3] = c4.w;
+                }
+            }
             // residual / aux tile: all 32 loads are issued up front into the (now dead) fragment registers
             u32x2 rres[32];
             if constexpr (USES_RES) {
@@ -398,10 +427,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                     for (int j = 0; j < 4; ++j) {
                         const unsigned voff = voff0 + (unsigned)((ha * 128 + mi * 16 + j) * P.N) * 2u;
                         float v[4];
+                        if constexpr (LNF) {
+                            const f32x4 sp = lst[ha * 8 + mi * 2 + (j >> 1)];  // two rows' (mean * rstd, rstd)
+                            const float mr = (j & 1) ? sp[2] : sp[0], rs = (j & 1) ? sp[3] : sp[1];
 #pragma unroll
-                        for (int hb = 0; hb < 2; ++hb)
+                            for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                            for (int ni = 0; ni < 2; ++ni) v[hb * 2 + ni] = acc[ha][mi][hb][ni][j] + bias[hb * 2 + ni];
+                                for (int ni = 0; ni < 2; ++ni)
+                                    v[hb * 2 + ni] = fmaf(rs, acc[ha][mi][hb][ni][j], fmaf(-mr, lnc[hb * 2 + ni], bias[hb * 2 + ni]));
+                        } else {
+#pragma unroll
+                            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                                for (int ni = 0; ni < 2; ++ni) v[hb * 2 + ni] = acc[ha][mi][hb][ni][j] + bias[hb * 2 + ni];
+                        }
                         if constexpr (OUTM == 2) {
                             bf16x4 pv;
 #pragma unroll
@@ -454,16 +493,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance team 1's extra barrier
 }
 
-template <int EPI, int OUTM>
+template <int EPI, int OUTM, bool LNF = false>
 int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
-    auto kern = gemm8p_persist_kernel<EPI, OUTM>;
+    auto kern = gemm8p_persist_kernel<EPI, OUTM, LNF>;
     static bool attr_set = false;
     if (!attr_set) {
-        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (LNF ? 2048 : 0)));
         attr_set = true;
     }
     const int G = P.T < ncu ? P.T : ncu;
-    hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), LDS_BYTES, stream, P);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), LDS_BYTES + (LNF ? 2048 : 0), stream, P);
     VIT_CHECK_HIP(hipGetLastError());
     return VIT_OK;
 }
@@ -519,6 +558,16 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
     VIT_REQUIRE(!(f32out && (epi != VIT_EPI_BIAS || pre)), "gemm8p: fp32 output only with the plain epilogue");
     VIT_REQUIRE(!pre || epi == VIT_EPI_GELU || epi == VIT_EPI_QUICK_GELU, "gemm8p: pre-activation output needs an activation epilogue");
     VIT_REQUIRE((size_t)256 * N * (f32out ? 4 : 2) < ((size_t)1 << 31), "gemm8p: N too large");
+    if (ext && ext->ln_stats) {
+        VIT_REQUIRE(ext->ln_colsum != nullptr && !f32out && !pre && splits == 1, "gemm8p: folded LayerNorm takes the plain bf16 epilogues only");
+        P.ln_stats = ext->ln_stats; P.ln_c = ext->ln_colsum;
+        switch (epi) {
+            case VIT_EPI_BIAS: return g8::launch_persist<VIT_EPI_BIAS, 0, true>(P, ncu, stream);
+            case VIT_EPI_GELU: return g8::launch_persist<VIT_EPI_GELU, 0, true>(P, ncu, stream);
+            case VIT_EPI_QUICK_GELU: return g8::launch_persist<VIT_EPI_QUICK_GELU, 0, true>(P, ncu, stream);
+        }
+        return vit_set_error(VIT_E_INVALID, "gemm8p: folded LayerNorm with epilogue %d", epi);
+    }
     if (f32out) {
         int rc = g8::launch_persist<VIT_EPI_BIAS, 1>(P, ncu, stream);
         if (rc != VIT_OK || splits == 1) return rc;

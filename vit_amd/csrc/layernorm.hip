@@ -81,6 +81,76 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Row statistics only: stats[row] = (mean * rstd, rstd). Used when the normalisation itself is folded
+// into the GEMM that consumes the row (vit_capi.hip "LayerNorm folded into the next GEMM"): the row is
+// read once and nothing but 8 bytes per row is written.
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, float2* __restrict__ stats, int rows, int dim,
+                                                       int64_t xs, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const float inv_d = 1.0f / (float)dim;
+    for (int row = wave_in_grid; row < rows; row += nwaves) {
+        const T* xr = x + (size_t)row * xs;
+        f32x4 v[NIT];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < dim) {
+                v[it] = Vec4<T>::load(xr + c);
+                s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+            } else {
+                v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float ss = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < dim) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[it][e] - mean;
+                    ss += d * d;
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_d + eps);
+        if (lane == 0) stats[row] = make_float2(mean * rstd, rstd);
+    }
+}
+
+// Fold a LayerNorm's affine part into the Linear that follows it. With xh = (x - mean) * rstd:
+//   (xh * gamma + beta) W^T + bias = rstd * (x Wg^T) - (mean * rstd) * c + d,
+//   Wg[n,k] = W[n,k] * gamma[k] (rounded to bf16 like any weight), c[n] = sum_k Wg[n,k] (of the ROUNDED
+//   values, so the mean term cancels exactly what the MFMA multiplies), d[n] = bias[n] + sum_k W[n,k] beta[k].
+// One wave per output row n.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, int64_t pitch, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      bf16_t* __restrict__ Wg, float* __restrict__ c, float* __restrict__ d, int N,
+                                                      int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;  // whole wave
+    float sc = 0.f, sd = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)W[(size_t)n * pitch + k];
+        const bf16_t wg = (bf16_t)(w * gamma[k]);
+        Wg[(size_t)n * pitch + k] = wg;
+        sc += (float)wg;
+        sd += w * beta[k];
+    }
+    sc = wave_sum(sc);
+    sd = wave_sum(sd);
+    if (lane == 0) {
+        c[n] = sc;
+        d[n] = sd + (bias ? bias[n] : 0.f);
+    }
+}
+
 template <typename T, int NIT>
 int launch_ln_t(const void* x, const float* g, const float* b, void* y, int rows, int dim, int64_t xs, int64_t ys,
                 float eps, hipStream_t stream) {
@@ -172,6 +242,33 @@ int launch_layernorm(const void* x, const float* g, const float* b, void* y, int
     if (dtype == VIT_BF16) return launch_ln_nit<bf16_t>(x, g, b, y, rows, dim, xs, ys, eps, stream);
     if (dtype == VIT_F32) return launch_ln_nit<float>(x, g, b, y, rows, dim, xs, ys, eps, stream);
     return vit_set_error(VIT_E_INVALID, "layernorm: bad dtype %d", dtype);
+}
+
+int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, float eps, int dtype, hipStream_t stream) {
+    VIT_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && xs % 4 == 0 && dim <= 2048, "ln_stats: bad shape rows=%d dim=%d", rows, dim);
+    VIT_REQUIRE(dtype == VIT_BF16, "ln_stats: bf16 only");
+    int blocks = ceil_div(rows, 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const bf16_t* xp = (const bf16_t*)x;
+    float2* sp = (float2*)stats;
+#define VIT_LN_STATS_CASE(NIT) \
+    case NIT: hipLaunchKernelGGL((ln_stats_kernel<bf16_t, NIT>), dim3(blocks), dim3(256), 0, stream, xp, sp, rows, dim, xs, eps); break;
+    switch (ceil_div(dim, 256)) {
+        VIT_LN_STATS_CASE(1) VIT_LN_STATS_CASE(2) VIT_LN_STATS_CASE(3) VIT_LN_STATS_CASE(4)
+        VIT_LN_STATS_CASE(5) VIT_LN_STATS_CASE(6) VIT_LN_STATS_CASE(7) VIT_LN_STATS_CASE(8)
+    }
+#undef VIT_LN_STATS_CASE
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+int launch_ln_fold(const void* W, int64_t pitch, const float* gamma, const float* beta, const float* bias, void* Wg, float* c,
+                   float* d, int N, int K, hipStream_t stream) {
+    VIT_REQUIRE(N > 0 && K > 0 && pitch >= K, "ln_fold: bad shape");
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, stream, (const bf16_t*)W, pitch, gamma, beta, bias,
+                       (bf16_t*)Wg, c, d, N, K);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
 }
 
 int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t stream) {

@@ -211,6 +211,31 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
         w.wqkv = A + lo[l].wqkv; w.wo = A + lo[l].wo; w.w1 = A + lo[l].w1; w.w2 = A + lo[l].w2;
     }
     ctx->n_missing = (int)ctx->slots.size();
+    // LayerNorm folded into the QKV / fc1 GEMMs (bf16 contexts). The folded copies live in their own arena,
+    // allocated here so that no forward ever allocates.
+    ctx->fold_arena = nullptr;
+    ctx->fold_dirty = true;
+    const char* fl = getenv("VIT_AMD_FUSE_LN");
+    ctx->ln_fuse = (T == VIT_BF16 && !(fl && atoi(fl) == 0)) ? 1 : 0;
+    if (ctx->ln_fuse) {
+        const size_t per = align256((size_t)3 * D * D * 2) + align256((size_t)F * D * 2) + 2 * align256((size_t)3 * D * 4) +
+                           2 * align256((size_t)F * 4);
+        e = hipMalloc((void**)&ctx->fold_arena, per * L);
+        if (e != hipSuccess) {
+            (void)hipFree(ctx->arena);
+            delete ctx;
+            return vit_set_error(VIT_E_NOMEM, "vit_create: hipMalloc(%zu) for the folded weights failed: %s", per * L, hipGetErrorString(e));
+        }
+        ctx->folds.resize(L);
+        unsigned char* p = ctx->fold_arena;
+        auto take = [&](size_t bytes) { unsigned char* r = p; p += align256(bytes); return r; };
+        for (int l = 0; l < L; ++l) {
+            LnFold& f = ctx->folds[l];
+            f.wqkv = take((size_t)3 * D * D * 2); f.w1 = take((size_t)F * D * 2);
+            f.cqkv = (float*)take((size_t)3 * D * 4); f.dqkv = (float*)take((size_t)3 * D * 4);
+            f.c1 = (float*)take((size_t)F * 4); f.d1 = (float*)take((size_t)F * 4);
+        }
+    }
     // two-stream forward: on by default for bf16 contexts, VIT_AMD_DUAL_STREAM=0/1 overrides
     ctx->ev_fork = nullptr;
     for (int i = 0; i < vit_ctx::kMaxStreams - 1; ++i) { ctx->aux_stream[i] = nullptr; ctx->ev_join[i] = nullptr; }
@@ -242,6 +267,7 @@ extern "C" int vit_destroy(vit_ctx* ctx) {
         if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]);
     }
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->fold_arena) (void)hipFree(ctx->fold_arena);
     delete ctx;
     return VIT_OK;
 }
@@ -262,6 +288,7 @@ extern "C" int vit_load_weight(vit_ctx* ctx, const char* name, const void* src_d
         s.loaded = true;
         --ctx->n_missing;
     }
+    ctx->fold_dirty = true;
     return rc;
 }
 
@@ -280,7 +307,7 @@ extern "C" int vit_missing_weights(vit_ctx* ctx, const char** first_missing) {
 // ---------------------------------------------------------------- forward
 namespace {
 struct Workspace {
-    size_t x, ln, qkv, ctxv, h, pix, total;
+    size_t x, ln, qkv, ctxv, h, pix, stats, total;
 };
 Workspace plan_workspace(const vit_ctx* ctx, int batch) {
     const vit_config& c = ctx->cfg;
@@ -294,6 +321,7 @@ Workspace plan_workspace(const vit_ctx* ctx, int batch) {
     w.ctxv = take(M * c.hidden_size * es);
     w.h = take(M * c.intermediate_size * es);
     w.pix = take((size_t)batch * c.num_channels * c.image_size * c.image_size * es);
+    w.stats = take(M * 8);  // folded LayerNorm: (mean * rstd, rstd) per row
     w.total = cur;
     return w;
 }
@@ -325,6 +353,23 @@ extern "C" size_t vit_workspace_bytes(const vit_ctx* ctx, int batch) {
 static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
                          void* pooled_out, void* workspace, hipStream_t stream);
 
+// Folded LayerNorm (modeling_vit.py:274,281 feeding :216-218 / :250): LN(x) W^T + b is computed as
+// rstd * (x Wg^T) - (mean * rstd) * c + d inside the GEMM's epilogue, so the normalised activations are never
+// written or read: a statistics pass over x (8 bytes out per row) replaces the LayerNorm kernel. The folded
+// copies are rebuilt on the forward's stream after any weight change (load, SGD step).
+static int refresh_folds(vit_ctx* ctx, hipStream_t stream) {
+    if (!ctx->ln_fuse || !ctx->fold_dirty) return VIT_OK;
+    const int D = ctx->cfg.hidden_size, F = ctx->cfg.intermediate_size;
+    for (int l = 0; l < ctx->cfg.num_hidden_layers; ++l) {
+        const LayerW& lw = ctx->layers[l];
+        const LnFold& f = ctx->folds[l];
+        VIT_TRY(launch_ln_fold(lw.wqkv, D, lw.ln1_g, lw.ln1_b, lw.bqkv, f.wqkv, f.cqkv, f.dqkv, 3 * D, D, stream));
+        VIT_TRY(launch_ln_fold(lw.w1, D, lw.ln2_g, lw.ln2_b, lw.b1, f.w1, f.c1, f.d1, F, D, stream));
+    }
+    ctx->fold_dirty = false;
+    return VIT_OK;
+}
+
 extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
                            void* pooled_out, void* workspace, size_t workspace_bytes, void* stream_) {
     VIT_REQUIRE(ctx && pixels_dev && hidden_out && workspace, "vit_forward: null argument");
@@ -342,6 +387,7 @@ extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype
     if (workspace_bytes < need)
         return vit_set_error(VIT_E_NOMEM, "vit_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
     hipStream_t stream = (hipStream_t)stream_;
+    VIT_TRY(refresh_folds(ctx, stream));
     const int k = num_chunks(ctx, batch);
     if (k == 1) return forward_range(ctx, pixels_dev, pixel_dtype, batch, hidden_out, pooled_out, workspace, stream);
 
@@ -385,6 +431,10 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
     void* h = ws + w.h;
     const bool clip = c.variant == VIT_VARIANT_CLIP;
     const int act_epi = c.hidden_act == VIT_ACT_GELU ? VIT_EPI_GELU : VIT_EPI_QUICK_GELU;
+    float* stats = (float*)(ws + w.stats);
+    // folded LayerNorm at every batch size (both GEMM kernels carry the epilogue and give the same bits, so a
+    // sub-batch reproduces the rows of the full batch)
+    const bool fuse = ctx->ln_fuse && !ctx->fold_dirty;
 
     // embeddings (modeling_vit.py:129-161 / modeling_clip.py:202-218)
     const void* pix = pixels_dev;
@@ -403,13 +453,28 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
         const LayerW& lw = ctx->layers[l];
         const bool last = (l == c.num_hidden_layers - 1);
         // x + Attn(LN1(x))   (modeling_vit.py:273-277)
-        VIT_TRY(launch_layernorm(x, lw.ln1_g, lw.ln1_b, ln, M, D, D, D, c.layer_norm_eps, T, stream));
-        VIT_TRY(launch_gemm(ln, lw.wqkv, lw.bqkv, nullptr, qkv, M, 3 * D, D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
+        if (fuse) {
+            GemmExt e{};
+            e.ln_stats = stats; e.ln_colsum = ctx->folds[l].cqkv;
+            VIT_TRY(launch_ln_stats(x, stats, M, D, D, c.layer_norm_eps, T, stream));
+            VIT_TRY(launch_gemm(x, ctx->folds[l].wqkv, ctx->folds[l].dqkv, nullptr, qkv, M, 3 * D, D, VIT_EPI_BIAS, T, nullptr,
+                                nullptr, stream, &e));
+        } else {
+            VIT_TRY(launch_layernorm(x, lw.ln1_g, lw.ln1_b, ln, M, D, D, D, c.layer_norm_eps, T, stream));
+            VIT_TRY(launch_gemm(ln, lw.wqkv, lw.bqkv, nullptr, qkv, M, 3 * D, D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
+        }
         VIT_TRY(launch_attention(qkv, cx, batch, N, H, ctx->dh, T, stream));
         VIT_TRY(launch_gemm(cx, lw.wo, lw.bo, x, x, M, D, D, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream));
         // x + MLP(LN2(x))    (modeling_vit.py:280-284)
-        VIT_TRY(launch_layernorm(x, lw.ln2_g, lw.ln2_b, ln, M, D, D, D, c.layer_norm_eps, T, stream));
-        VIT_TRY(launch_gemm(ln, lw.w1, lw.b1, nullptr, h, M, F, D, act_epi, T, nullptr, nullptr, stream));
+        if (fuse) {
+            GemmExt e{};
+            e.ln_stats = stats; e.ln_colsum = ctx->folds[l].c1;
+            VIT_TRY(launch_ln_stats(x, stats, M, D, D, c.layer_norm_eps, T, stream));
+            VIT_TRY(launch_gemm(x, ctx->folds[l].w1, ctx->folds[l].d1, nullptr, h, M, F, D, act_epi, T, nullptr, nullptr, stream, &e));
+        } else {
+            VIT_TRY(launch_layernorm(x, lw.ln2_g, lw.ln2_b, ln, M, D, D, D, c.layer_norm_eps, T, stream));
+            VIT_TRY(launch_gemm(ln, lw.w1, lw.b1, nullptr, h, M, F, D, act_epi, T, nullptr, nullptr, stream));
+        }
         // CLIP returns the un-normed stream: let the last fc2 write it straight to hidden_out
         void* dst = (clip && last) ? hidden_out : x;
         VIT_TRY(launch_gemm(h, lw.w2, lw.b2, x, dst, M, D, F, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream));

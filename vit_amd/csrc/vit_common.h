@@ -39,22 +39,7 @@ __device__ __forceinline__ float act_quick_gelu(float x) {
     return x / (1.0f + __expf(-1.702f * x));
 }
 
-// GELU for the bf16 kernels: same function as act_gelu_erf with erfc from Abramowitz-Stegun
-// 7.1.26 (|erf error| <= 1.5e-7, far below bf16 output resolution): 14 VALU ops, two of them
-// transcendental, no branches.  gelu(x) = max(x,0) - 0.5 |x| erfc(|x|/sqrt2).
-__device__ __forceinline__ float act_gelu_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
-    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
-    p = fmaf(p, t, 0.5f * 1.421413741f);
-    p = fmaf(p, t, 0.5f * -0.284496736f);
-    p = fmaf(p, t, 0.5f * 0.254829592f);
-    p = p * t * e;
-    return fmaxf(x, 0.0f) - ax * p;
-}
-
-// GELU on two elements at once for the persistent GEMM's epilogue, where the activation is the
+// GELU of the bf16 kernels, on two elements at once: in the persistent GEMM's epilogue the activation is the
 // exposed cost (128 elements per lane and tile): no transcendental, and the multiplies / FMAs
 // are written on float2 so they become v_pk_mul_f32 / v_pk_fma_f32 (2 elements per issue).
 //   erf(z) = z h(z^2) with h a degree-8 minimax-style fit on z^2 in [0, 9] (Chebyshev-node least
@@ -62,25 +47,30 @@ __device__ __forceinline__ float act_gelu_as(float x) {
 // |gelu error| <= 7.7e-5 over all x (largest near |x| = 4, where one bf16 ulp of the result is
 // 1.6e-2; <= 2e-5 for |x| <= 2), i.e. below the bf16 rounding of the stored activation.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, float c) { return __builtin_elementwise_fma(a, b, f32x2{c, c}); }
 __device__ __forceinline__ f32x2 act_gelu_pk(f32x2 x) {
+    // every multiply-add is an explicit fma: the same bits from every kernel that inlines this,
+    // whatever the compiler would have contracted
     const f32x2 z = x * 0.70710678118654752440f;
     f32x2 u = z * z;
     u.x = fminf(u.x, 9.0f);
     u.y = fminf(u.y, 9.0f);
-    f32x2 p = u * 4.9182759198629356e-08f + -2.2677306787954876e-06f;
-    p = p * u + 4.6147291868692264e-05f;
-    p = p * u + -0.0005535572418011725f;
-    p = p * u + 0.004437862429767847f;
-    p = p * u + -0.02564961276948452f;
-    p = p * u + 0.11186250299215317f;
-    p = p * u + -0.3758186101913452f;
-    p = p * u + 1.1283628940582275f;
+    f32x2 p = pk_fma(u, f32x2{4.9182759198629356e-08f, 4.9182759198629356e-08f}, -2.2677306787954876e-06f);
+    p = pk_fma(p, u, 4.6147291868692264e-05f);
+    p = pk_fma(p, u, -0.0005535572418011725f);
+    p = pk_fma(p, u, 0.004437862429767847f);
+    p = pk_fma(p, u, -0.02564961276948452f);
+    p = pk_fma(p, u, 0.11186250299215317f);
+    p = pk_fma(p, u, -0.3758186101913452f);
+    p = pk_fma(p, u, 1.1283628940582275f);
     f32x2 s = z * p;
     s.x = __builtin_amdgcn_fmed3f(s.x, -1.0f, 1.0f);
     s.y = __builtin_amdgcn_fmed3f(s.y, -1.0f, 1.0f);
     const f32x2 t = x * 0.5f;
-    return t * s + t;
+    return __builtin_elementwise_fma(t, s, t);
 }
+// the same function on one element (generic GEMM kernel): identical bits to act_gelu_pk
+__device__ __forceinline__ float act_gelu_poly(float x) { return act_gelu_pk(f32x2{x, x}).x; }
 
 // gelu'(x) = Phi(x) + x phi(x), same erfc approximation (backward of ViTMLP's activation)
 __device__ __forceinline__ float act_dgelu_as(float x) {
@@ -109,7 +99,7 @@ __device__ __forceinline__ float act_grad(float aux) {
 // activations of the bf16 kernels (fp32 parity mode keeps erff)
 template <int EPI>
 __device__ __forceinline__ float apply_act_bf16(float v) {
-    if constexpr (EPI == VIT_EPI_GELU) return act_gelu_as(v);
+    if constexpr (EPI == VIT_EPI_GELU) return act_gelu_poly(v);
     if constexpr (EPI == VIT_EPI_QUICK_GELU) return act_quick_gelu(v);
     return v;
 }
@@ -144,6 +134,11 @@ struct GemmExt {
     int split_k;   // > 1 (fp32 output, persistent kernel only): K is cut into split_k ranges, each
                    // written to its own fp32 slab, then summed in a fixed order (reproducible)
     float* slabs;  // split_k * M * N floats
+    // LayerNorm folded into this GEMM (persistent kernel, bias / activation epilogues): A is the
+    // UN-normalised row, W carries gamma, and the epilogue computes rstd * acc - (mean * rstd) * c + bias
+    // with ln_stats[row] = (mean * rstd, rstd) and c = ln_colsum (see ln_fold_kernel, layernorm.hip)
+    const float* ln_stats;   // [M][2]
+    const float* ln_colsum;  // [N]
 };
 
 // C = epi(A W^T + bias (+res)); `patch` non-null => A is the pixel tensor, rows are patches,
@@ -166,6 +161,10 @@ int launch_layernorm_bwd(const void* x, const void* dy, const float* gamma, cons
 constexpr int kLnBwdMaxBlocks = 2048;
 int launch_embed_grad(const void* dx0, float* dpos, float* dcls, int B, int N, int D, hipStream_t stream);
 int launch_sgd(float* master, const float* grad, void* copy_bf16, float lr, int64_t n, hipStream_t stream);
+// LayerNorm folded into the next GEMM (layernorm.hip): per-row (mean * rstd, rstd), and the weight fold
+int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, float eps, int dtype, hipStream_t stream);
+int launch_ln_fold(const void* W, int64_t pitch, const float* gamma, const float* beta, const float* bias, void* Wg, float* c,
+                   float* d, int N, int K, hipStream_t stream);
 int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t stream);
 int launch_im2col_t(const void* pixels, int pixel_dtype, void* dst, int R, int Rpad, const PatchGeom* g, int kpad,
                     hipStream_t stream);

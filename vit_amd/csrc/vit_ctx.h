@@ -20,6 +20,13 @@ struct LayerW {
     void *wqkv, *wo, *w1, *w2;
 };
 
+// LayerNorm folded into the GEMM that follows it (inference forward, bf16): per layer the gamma-scaled
+// copies of the QKV / fc1 weights, their column sums c and the folded biases d (ln_fold_kernel, layernorm.hip)
+struct LnFold {
+    void *wqkv, *w1;
+    float *cqkv, *dqkv, *c1, *d1;
+};
+
 // fp32-arena element offsets of one layer's tensors (gradients and master weights share them)
 struct LayerG {
     size_t ln1_g, ln1_b, ln2_g, ln2_b, bqkv, bo, b1, b2, wqkv, wo, w1, w2;
@@ -56,4 +63,9 @@ struct vit_ctx {
     hipStream_t aux_stream[kMaxStreams - 1];
     hipEvent_t ev_fork, ev_join[kMaxStreams - 1];
     int nstreams;  // 1 = single stream
+    // folded LayerNorm (vit_capi.hip): copies are refreshed on the forward's stream whenever a weight changed
+    int ln_fuse;               // 0 = off (fp32 contexts, D not a legal K of the persistent GEMM, VIT_AMD_FUSE_LN=0)
+    unsigned char* fold_arena;
+    std::vector<LnFold> folds;
+    bool fold_dirty;
 };

@@ -457,6 +457,7 @@ extern "C" int vit_sgd_step(vit_ctx* ctx, const void* grads_, float lr, void* st
     VIT_REQUIRE(ctx->train && grads_, "vit_sgd_step: call vit_train_init first");
     hipStream_t stream = (hipStream_t)stream_;
     VIT_TRY(launch_sgd(ctx->train->master, (const float*)grads_, nullptr, lr, (int64_t)ctx->g_total, stream));
+    ctx->fold_dirty = true;  // the inference forward's folded LayerNorm copies are stale now
     for (auto& kv : ctx->slots) {
         const Slot& s = kv.second;
         VIT_TRY(launch_convert_2d(ctx->train->master + s.goff, VIT_F32, ctx->arena + s.offset, s.dtype, s.rows, s.pitch,
