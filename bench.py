@@ -75,15 +75,20 @@ def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
     pw = t((d, cfg.num_channels, cfg.patch_size, cfg.patch_size), "pw", 0.02)
     cls, pos = synth.normal((d,), 11, "cls", device=dev), synth.normal((n, d), 11, "pos", device=dev)
     L = cfg.num_hidden_layers
+    # vit_forward folds LN1 / LN2 into the QKV / fc1 GEMMs: a statistics pass over x, then the GEMM on the
+    # un-normalised rows with the row terms in its epilogue (include/vit_amd.h, vit_gemm_ln_folded)
+    stats = ops.layer_norm_stats(x, cfg.layer_norm_eps)
+    fqkv, f1 = ops.layer_norm_fold(wqkv, g, b, bqkv), ops.layer_norm_fold(w1, g, b, b1)
     specs = [  # name, launches per forward, callable, flops per launch, bytes per launch (HBM-bound kernels)
-        ("gemm_qkv", L, lambda: ops.linear(x, wqkv, bqkv), 2 * m * 3 * d * d, None),
+        ("gemm_qkv", L, lambda: ops.linear_ln_folded(x, fqkv, stats), 2 * m * 3 * d * d, None),
         ("gemm_o_proj_res", L, lambda: ops.linear(x, wo, bo, residual=x), 2 * m * d * d, None),
-        ("gemm_fc1_gelu", L, lambda: ops.linear(x, w1, b1, activation=cfg.hidden_act), 2 * m * f * d, None),
+        ("gemm_fc1_gelu", L, lambda: ops.linear_ln_folded(x, f1, stats, cfg.hidden_act), 2 * m * f * d, None),
         ("gemm_fc2_res", L, lambda: ops.linear(hid, w2, bo, residual=x), 2 * m * d * f, None),
         # attention at N = 197, dh = 64 is 99 FLOP per byte (Q, K, V read once, output written once)
         # against a machine balance of ~310: its roofline is HBM; both figures are reported
         ("attention", L, lambda: ops.attention(qkv, h), 4 * batch * h * n * n * cfg.head_dim, 4 * m * d * 2),
-        ("layernorm", 2 * L + 1, lambda: ops.layer_norm(x, g, b, cfg.layer_norm_eps), None, 2 * m * d * 2),
+        ("layernorm_stats", 2 * L, lambda: ops.layer_norm_stats(x, cfg.layer_norm_eps), None, m * d * 2 + m * 8),
+        ("layernorm", 1, lambda: ops.layer_norm(x, g, b, cfg.layer_norm_eps), None, 2 * m * d * 2),
         ("patch_embed", 1, lambda: ops.patch_embed(px, pw, bo, cls, pos, cfg.patch_size),
          2 * batch * cfg.num_patches * cfg.patch_dim * d, None),
     ]

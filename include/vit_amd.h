@@ -111,7 +111,11 @@ size_t vit_workspace_bytes(const vit_ctx* ctx, int batch);
  * a stream the context owns (forked from and joined back into `stream` with events, so the call
  * keeps its stream semantics and stays graph-capturable): one half's kernels occupy the CUs the
  * other half's last round of GEMM tiles leaves idle (+5 % images/s at ViT-B/16 batch 256).
- * Environment VIT_AMD_STREAMS=1..4 at vit_create overrides the number of streams. */
+ * Environment VIT_AMD_STREAMS=1..4 at vit_create overrides the number of streams.
+ * VIT_BF16 contexts also fold LN1 / LN2 into the q/k/v and fc1 GEMMs (vit_gemm_ln_folded below): the context
+ * holds gamma-scaled copies of those weights and rebuilds them on `stream` at the next vit_forward after a
+ * vit_load_weight or vit_sgd_step. Every batch size gives the same bits for the same image. Environment
+ * VIT_AMD_FUSE_LN=0 at vit_create keeps LayerNorm a separate kernel. */
 int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
                 void* pooled_out, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -145,6 +149,28 @@ int vit_patch_embed_fwd(const void* pixels, const void* weight, const float* bia
                         const float* pos, void* x_out, int batch, int channels, int image, int patch,
                         int dim, int dtype, void* stream);
 int vit_patch_kpad(int channels, int patch, int dtype);
+
+/* ---- LayerNorm folded into the Linear that follows it (bf16). vit_forward computes LN1 -> q/k/v projection
+ * (MV:274 feeding MV:216-218) and LN2 -> fc1 (MV:281 feeding MV:250) this way: with xh = (x - mean) * rstd,
+ *   (xh * gamma + beta) W^T + b  =  rstd * (x Wg^T) - (mean * rstd) * c + d,
+ *   Wg[n,k] = W[n,k] * gamma[k],  c[n] = sum_k Wg[n,k],  d[n] = b[n] + sum_k W[n,k] * beta[k],
+ * so the normalised activations are never written: a statistics pass over x replaces the LayerNorm kernel and
+ * the GEMM's epilogue applies the two row terms. The three steps, exposed for parity tests and timing:
+ *  vit_layernorm_stats: stats[row] = (mean * rstd, rstd), biased variance, fp32 (same statistics as
+ *    vit_layernorm_fwd); x is [rows, dim] bf16 with the given row stride (elements).
+ *  vit_layernorm_fold: weight [out_dim, in_dim] bf16 -> weight_folded (same shape, bf16), colsum[out_dim] (sum of
+ *    the ROUNDED folded row, so the mean term cancels exactly what the MFMA multiplies), bias_folded[out_dim];
+ *    bias may be NULL.
+ *  vit_gemm_ln_folded: C[M,N] = act(rstd * (x Wg^T) - mean * rstd * c + d), epilogue VIT_EPI_BIAS / _GELU /
+ *    _QUICK_GELU. Same result as vit_layernorm_fwd followed by vit_gemm_bias_act up to bf16 rounding points
+ *    (the normalised row is not rounded to bf16 on the way). VIT_AMD_FUSE_LN=0 in the environment at vit_create
+ *    makes vit_forward use the two separate kernels instead. */
+int vit_layernorm_stats(const void* x, float* stats, int rows, int dim, int64_t x_row_stride, float eps, int dtype,
+                        void* stream);
+int vit_layernorm_fold(const void* weight, const float* gamma, const float* beta, const float* bias, void* weight_folded,
+                       float* colsum, float* bias_folded, int out_dim, int in_dim, void* stream);
+int vit_gemm_ln_folded(const void* x, const void* weight_folded, const float* bias_folded, const float* colsum,
+                       const float* stats, void* C, int M, int N, int K, int epilogue, void* stream);
 
 /* ---- training-step kernels (VIT_BF16 activations, fp32 statistics and parameter gradients).
  * The reference has no training code at all; these are the backward

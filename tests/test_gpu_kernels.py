@@ -198,3 +198,58 @@ def test_patch_embed(b, c, img, p, d, dtype, with_bias):
     assert tuple(out.shape) == (b, n, d)
     assert rel_err(out, ref) < (1e-5 if dtype == torch.float32 else BF16_TOL)
     assert min_row_cosine(out, ref) > 0.9999
+
+
+# ------------------------------------------------------------------ LayerNorm folded into the next Linear
+def test_layer_norm_stats_matches_torch():
+    x = q(rnd((1000, 768), "st.x") * 3 + 0.7)
+    st = ops.layer_norm_stats(x.to(DEV, torch.bfloat16), 1e-6).cpu()
+    mean = x.mean(-1)
+    rstd = 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-6)
+    assert rel_err(st[:, 1], rstd) < 1e-5
+    assert rel_err(st[:, 0], mean * rstd) < 1e-5
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 192, 128), (5600, 768, 256), (5555, 776, 384), (1576, 3072, 768)])
+@pytest.mark.parametrize("act", [None, "gelu", "quick_gelu"])
+def test_linear_ln_folded_matches_layernorm_then_linear(m, n, k, act):
+    """vit_layernorm_stats + vit_layernorm_fold + vit_gemm_ln_folded == act(linear(layer_norm(x))) (fp32 torch),
+    on the generic tile kernel (small) and the persistent kernel (big), ragged edges included; and the two
+    kernels give the same bits for the same rows."""
+    eps = 1e-6
+    x = q(rnd((m, k), "f.x") * 2 + 0.5)
+    w, b = q(rnd((n, k), "f.w", 0.05)), rnd((n,), "f.b", 0.3)
+    g, be = 1 + 0.3 * rnd((k,), "f.g"), 0.2 * rnd((k,), "f.be")
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (k,), g, be, eps), w, b)
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    elif act == "quick_gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    xd = x.to(DEV, torch.bfloat16)
+    folded = ops.layer_norm_fold(w.to(DEV, torch.bfloat16), g.to(DEV), be.to(DEV), b.to(DEV))
+    stats = ops.layer_norm_stats(xd, eps)
+    out = ops.linear_ln_folded(xd, folded, stats, act)
+    assert rel_err(out, ref) < BF16_TOL
+    assert min_row_cosine(out, ref) > 0.9999
+    # unfolded two-kernel path for scale: the folded one is at least as close to fp32
+    two = ops.linear(ops.layer_norm(xd, g.to(DEV), be.to(DEV), eps), w.to(DEV), b.to(DEV), activation=act)
+    assert rel_err(out, ref) <= 1.2 * rel_err(two, ref) + 1e-4
+    # a small slice of rows runs on the generic kernel: same bits
+    sub = ops.linear_ln_folded(xd[:40].contiguous(), folded, stats[:40].contiguous(), act)
+    assert torch.equal(sub, out[:40])
+
+
+def test_layer_norm_stats_and_folded_gemm_are_row_position_independent():
+    """A row's statistics and its folded-GEMM output must not depend on where the row sits (which of a wave's
+    row slots, which tile): permuted input rows give the permuted output bit for bit, and repeats are identical."""
+    m, k, n = 25216, 768, 2304
+    x = (rnd((m, k), "pp.x") * 2 + 0.5).to(DEV, torch.bfloat16)
+    perm = torch.randperm(m, generator=torch.Generator().manual_seed(3)).to(DEV)
+    st = ops.layer_norm_stats(x, 1e-12)
+    assert torch.equal(ops.layer_norm_stats(x[perm].contiguous(), 1e-12), st[perm])
+    assert torch.equal(ops.layer_norm_stats(x, 1e-12), st)
+    folded = ops.layer_norm_fold(rnd((n, k), "pp.w", 0.02).to(DEV, torch.bfloat16), (1 + 0.1 * rnd((k,), "pp.g")).to(DEV),
+                                 (0.1 * rnd((k,), "pp.b")).to(DEV), (0.1 * rnd((n,), "pp.c")).to(DEV))
+    out = ops.linear_ln_folded(x, folded, st)
+    assert torch.equal(ops.linear_ln_folded(x, folded, st), out)
+    assert torch.equal(ops.linear_ln_folded(x[perm].contiguous(), folded, st[perm].contiguous()), out[perm])

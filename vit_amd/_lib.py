@@ -62,6 +62,11 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_void_p]),
     "vit_patch_kpad": (c_int, [c_int, c_int, c_int]),
     "vit_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "vit_layernorm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_int, c_void_p]),
+    "vit_layernorm_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_void_p]),
+    "vit_gemm_ln_folded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_void_p]),
     "vit_gemm_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_void_p]),
     "vit_attention_fwd_train": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

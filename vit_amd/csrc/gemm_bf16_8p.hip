@@ -242,16 +242,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         constexpr int BUF = decltype(BUFC)::value, MODE = decltype(MODEC)::value;
         constexpr bool FIRST = decltype(FIRSTC)::value;
         using Z = std::integral_constant<bool, FIRST>;
+        // LNF, last K-tile of a tile: this tile's 256 x (mean * rstd, rstd) go to LDS behind the ring, one 4-byte
+        // DMA per lane (wave w brings dwords 64w..64w+63). Issued BEFORE the eight half-tile stage instructions of
+        // this K-tile, so the vmcnt(8) of ph4 retires it in every wave, and ph4's two barriers separate that wait
+        // from the epilogue, where the waves read each other's pieces.
+        if constexpr (LNF && MODE == 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Sr, LDS_PTR(smem + LDS_BYTES + wave * 256), 4, lane * 4, wave * 256, 0, 0);
         // ph1: (A0,B0)
         read_b(BUF, 0);
         read_a(BUF, 0);
         stage_b(1, BUF ^ 1, MODE == 2 ? 0 : t + 1);
         if constexpr (!FIRST) G8_WAIT_VM(6);
-        // LNF, last K-tile of a tile: this tile's 256 x (mean * rstd, rstd) go to LDS behind the ring, one 4-byte
-        // DMA per lane (wave w brings dwords 64w..64w+63). Older than the six half-tile stages that follow, so the
-        // vmcnt(8) of ph4 retires it, two barriers before the epilogue reads it.
-        if constexpr (LNF && MODE == 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Sr, LDS_PTR(smem + LDS_BYTES + wave * 256), 4, lane * 4, wave * 256, 0, 0);
         G8P_SECTION(0, 0, Z{});
         // ph2: (A0,B1)
         read_b(BUF, 1);
@@ -430,11 +431,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                         if constexpr (LNF) {
                             const f32x4 sp = lst[ha * 8 + mi * 2 + (j >> 1)];  // two rows' (mean * rstd, rstd)
                             const float mr = (j & 1) ? sp[2] : sp[0], rs = (j & 1) ? sp[3] : sp[1];
+                            // two packed fmas per column pair (same bits as the fmaf chain of the generic kernel)
 #pragma unroll
-                            for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                                for (int ni = 0; ni < 2; ++ni)
-                                    v[hb * 2 + ni] = fmaf(rs, acc[ha][mi][hb][ni][j], fmaf(-mr, lnc[hb * 2 + ni], bias[hb * 2 + ni]));
+                            for (int hb = 0; hb < 2; ++hb) {
+                                const f32x2 t = __builtin_elementwise_fma(f32x2{-mr, -mr}, f32x2{lnc[hb * 2], lnc[hb * 2 + 1]},
+                                                                          f32x2{bias[hb * 2], bias[hb * 2 + 1]});
+                                const f32x2 r2 = __builtin_elementwise_fma(f32x2{rs, rs}, f32x2{acc[ha][mi][hb][0][j], acc[ha][mi][hb][1][j]}, t);
+                                v[hb * 2] = r2.x;
+                                v[hb * 2 + 1] = r2.y;
+                            }
                         } else {
 #pragma unroll
                             for (int hb = 0; hb < 2; ++hb)

@@ -87,39 +87,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 template <typename T, int NIT>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, float2* __restrict__ stats, int rows, int dim,
                                                        int64_t xs, float eps) {
+    constexpr int R = 4;  // rows per wave and step: a read-only pass needs more bytes in flight than one row per wave
     const int lane = threadIdx.x & 63;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
     const float inv_d = 1.0f / (float)dim;
-    for (int row = wave_in_grid; row < rows; row += nwaves) {
-        const T* xr = x + (size_t)row * xs;
-        f32x4 v[NIT];
-        float s = 0.f;
+    for (int row0 = wave_in_grid * R; row0 < rows; row0 += nwaves * R) {
+        f32x4 v[R][NIT];
+        float s[R];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int c = (it * 64 + lane) * 4;
-            if (c < dim) {
-                v[it] = Vec4<T>::load(xr + c);
-                s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
-            } else {
-                v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r < rows ? row0 + r : rows - 1;  // the tail re-reads the last row
+            const T* xr = x + (size_t)row * xs;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = (it * 64 + lane) * 4;
+                v[r][it] = c < dim ? Vec4<T>::load(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        const float mean = wave_sum(s) * inv_d;
-        float ss = 0.f;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int c = (it * 64 + lane) * 4;
-            if (c < dim) {
+        for (int r = 0; r < R; ++r) {
+            s[r] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = v[it][e] - mean;
-                    ss += d * d;
+            for (int it = 0; it < NIT; ++it) s[r] += (v[r][it][0] + v[r][it][1]) + (v[r][it][2] + v[r][it][3]);
+        }
+        float mean[R], ss[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) * inv_d;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ss[r] = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = (it * 64 + lane) * 4;
+                if (c < dim) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[r][it][e] - mean[r];
+                        ss[r] = fmaf(d, d, ss[r]);
+                    }
                 }
             }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_d + eps);
-        if (lane == 0) stats[row] = make_float2(mean * rstd, rstd);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            // explicit fmaf / one code shape for every r: a row's statistics must not depend on which of the
+            // wave's four slots it landed in (a permuted batch gives the permuted output bit for bit)
+            const float rstd = 1.0f / sqrtf(fmaf(wave_sum(ss[r]), inv_d, eps));
+            if (lane == 0 && row0 + r < rows) stats[row0 + r] = make_float2(mean[r] * rstd, rstd);
+        }
     }
 }
 
@@ -247,8 +263,7 @@ int launch_layernorm(const void* x, const float* g, const float* b, void* y, int
 int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, float eps, int dtype, hipStream_t stream) {
     VIT_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && xs % 4 == 0 && dim <= 2048, "ln_stats: bad shape rows=%d dim=%d", rows, dim);
     VIT_REQUIRE(dtype == VIT_BF16, "ln_stats: bf16 only");
-    int blocks = ceil_div(rows, 4);
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int blocks = ceil_div(rows, 16);  // 4 waves x 4 rows: one step per wave, no grid-stride tail
     const bf16_t* xp = (const bf16_t*)x;
     float2* sp = (float2*)stats;
 #define VIT_LN_STATS_CASE(NIT) \

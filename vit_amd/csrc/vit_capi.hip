@@ -501,6 +501,30 @@ extern "C" int vit_layernorm_fwd(const void* x, const float* gamma, const float*
     return launch_layernorm(x, gamma, beta, y, rows, dim, x_row_stride, y_row_stride, eps, dtype, (hipStream_t)stream);
 }
 
+// ---- LayerNorm folded into the Linear that follows it (what vit_forward does for LN1 -> QKV, LN2 -> fc1)
+extern "C" int vit_layernorm_stats(const void* x, float* stats, int rows, int dim, int64_t x_row_stride, float eps, int dtype,
+                                   void* stream) {
+    VIT_REQUIRE(x && stats, "vit_layernorm_stats: null argument");
+    return launch_ln_stats(x, stats, rows, dim, x_row_stride, eps, dtype, (hipStream_t)stream);
+}
+
+extern "C" int vit_layernorm_fold(const void* weight, const float* gamma, const float* beta, const float* bias,
+                                  void* weight_folded, float* colsum, float* bias_folded, int out_dim, int in_dim,
+                                  void* stream) {
+    VIT_REQUIRE(weight && gamma && beta && weight_folded && colsum && bias_folded, "vit_layernorm_fold: null argument");
+    return launch_ln_fold(weight, in_dim, gamma, beta, bias, weight_folded, colsum, bias_folded, out_dim, in_dim, (hipStream_t)stream);
+}
+
+extern "C" int vit_gemm_ln_folded(const void* x, const void* weight_folded, const float* bias_folded, const float* colsum,
+                                  const float* stats, void* C, int M, int N, int K, int epilogue, void* stream) {
+    VIT_REQUIRE(x && weight_folded && bias_folded && colsum && stats && C, "vit_gemm_ln_folded: null argument");
+    VIT_REQUIRE(epilogue == VIT_EPI_BIAS || epilogue == VIT_EPI_GELU || epilogue == VIT_EPI_QUICK_GELU,
+                "vit_gemm_ln_folded: epilogue %d (bias, GELU or quick-GELU only)", epilogue);
+    GemmExt e{};
+    e.ln_stats = stats; e.ln_colsum = colsum;
+    return launch_gemm(x, weight_folded, bias_folded, nullptr, C, M, N, K, epilogue, VIT_BF16, nullptr, nullptr, (hipStream_t)stream, &e);
+}
+
 extern "C" int vit_gemm_bias_act(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,
                                  int N, int K, int epilogue, int dtype, void* stream) {
     VIT_REQUIRE(A && W && C, "vit_gemm_bias_act: null argument");

@@ -53,6 +53,46 @@ def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: f
     return y
 
 
+def layer_norm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
+    """Per-row ``(mean * rstd, rstd)`` of nn.LayerNorm's statistics, fp32 ``[..., 2]`` (bf16 input)."""
+    x = _bf16(x, "x")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    stats = torch.empty(*x.shape[:-1], 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().vit_layernorm_stats(x.data_ptr(), stats.data_ptr(), rows, d, d, float(eps), _lib.VIT_BF16, _stream()))
+    return stats
+
+
+def layer_norm_fold(weight: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: torch.Tensor | None = None):
+    """Fold a LayerNorm's affine part into the Linear after it: returns ``(weight * gamma [bf16], colsum, bias')``
+    for ``linear_ln_folded`` (include/vit_amd.h, vit_layernorm_fold)."""
+    w = _bf16(weight, "weight")
+    g, b0 = _f32(gamma, "gamma"), _f32(beta, "beta")
+    b = _f32(bias, "bias")
+    n, k = w.shape
+    wg = torch.empty_like(w)
+    c = torch.empty(n, dtype=torch.float32, device=w.device)
+    d = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().vit_layernorm_fold(w.data_ptr(), g.data_ptr(), b0.data_ptr(), _ptr(b), wg.data_ptr(), c.data_ptr(),
+                                              d.data_ptr(), n, k, _stream()))
+    return wg, c, d
+
+
+def linear_ln_folded(x: torch.Tensor, folded, stats: torch.Tensor, activation: str | None = None) -> torch.Tensor:
+    """``act(F.linear(layer_norm(x), weight, bias))`` from the UN-normalised ``x`` [bf16], the output of
+    ``layer_norm_fold`` and ``layer_norm_stats(x)`` (modeling_vit.py:274 + :216-218, :281 + :250-251)."""
+    x = _bf16(x, "x")
+    wg, c, d = folded
+    k, n = x.shape[-1], wg.shape[0]
+    if wg.shape[1] != k:
+        raise ValueError(f"linear_ln_folded: x has {k} features, weight expects {wg.shape[1]}")
+    m = x.numel() // k
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().vit_gemm_ln_folded(x.data_ptr(), wg.data_ptr(), d.data_ptr(), c.data_ptr(), stats.data_ptr(),
+                                              out.data_ptr(), m, n, k, _EPI[activation], _stream()))
+    return out
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, activation: str | None = None,
            residual: torch.Tensor | None = None) -> torch.Tensor:
     """``F.linear(x, weight, bias)`` followed by an activation or a residual add
