@@ -84,58 +84,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // Row statistics only: stats[row] = (mean * rstd, rstd). Used when the normalisation itself is folded
 // into the GEMM that consumes the row (vit_capi.hip "LayerNorm folded into the next GEMM"): the row is
 // read once and nothing but 8 bytes per row is written.
-template <typename T, int NIT>
-__global__ __launch_bounds__(256) void ln_stats_kernel(const T* __restrict__ x, float2* __restrict__ stats, int rows, int dim,
-                                                       int64_t xs, float eps) {
-    constexpr int R = 4;  // rows per wave and step: a read-only pass needs more bytes in flight than one row per wave
-    const int lane = threadIdx.x & 63;
+// Half a wave per row, 16-byte loads (8 bf16 per lane and step, NIT = ceil(dim / 256) steps), R row pairs per
+// wave in flight: a read-only pass wants wide loads and many bytes in flight.
+template <int NIT>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const bf16_t* __restrict__ x, float2* __restrict__ stats, int rows,
+                                                       int dim, int64_t xs, float eps) {
+    constexpr int R = 4;  // row pairs per wave
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
     const float inv_d = 1.0f / (float)dim;
-    for (int row0 = wave_in_grid * R; row0 < rows; row0 += nwaves * R) {
-        f32x4 v[R][NIT];
-        float s[R];
+    const int row0 = wave_in_grid * (2 * R);
+    if (row0 >= rows) return;  // whole wave
+    bf16x8 v[R][NIT];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = row0 + r < rows ? row0 + r : rows - 1;  // the tail re-reads the last row
-            const T* xr = x + (size_t)row * xs;
+    for (int r = 0; r < R; ++r) {
+        int row = row0 + 2 * r + half;
+        if (row > rows - 1) row = rows - 1;  // the tail re-reads the last row
+        const bf16_t* xr = x + (size_t)row * xs;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int c = (it * 64 + lane) * 4;
-                v[r][it] = c < dim ? Vec4<T>::load(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 32 + hl) * 8;
+            if (c < dim) {
+                v[r][it] = *(const bf16x8*)(xr + c);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[r][it][e] = (bf16_t)0.0f;
             }
         }
+    }
+    // sum over the 32 lanes of a half wave (xor 16 .. 1 stays inside the half)
+    auto half_sum = [](float a) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            s[r] = 0.f;
+        for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        return a;
+    };
+    // explicit fmaf and one code shape for every r: a row's statistics must not depend on which slot of the
+    // wave it landed in (a permuted batch gives the permuted output bit for bit)
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) s[r] += (v[r][it][0] + v[r][it][1]) + (v[r][it][2] + v[r][it][3]);
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const bf16x8 t = v[r][it];
+            s += (((float)t[0] + (float)t[1]) + ((float)t[2] + (float)t[3])) + (((float)t[4] + (float)t[5]) + ((float)t[6] + (float)t[7]));
         }
-        float mean[R], ss[R];
+        const float mean = half_sum(s) * inv_d;
+        float ss = 0.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) * inv_d;
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 32 + hl) * 8;
+            if (c < dim) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            ss[r] = 0.f;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int c = (it * 64 + lane) * 4;
-                if (c < dim) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = v[r][it][e] - mean[r];
-                        ss[r] = fmaf(d, d, ss[r]);
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)v[r][it][e] - mean;
+                    ss = fmaf(d, d, ss);
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            // explicit fmaf / one code shape for every r: a row's statistics must not depend on which of the
-            // wave's four slots it landed in (a permuted batch gives the permuted output bit for bit)
-            const float rstd = 1.0f / sqrtf(fmaf(wave_sum(ss[r]), inv_d, eps));
-            if (lane == 0 && row0 + r < rows) stats[row0 + r] = make_float2(mean[r] * rstd, rstd);
-        }
+        const float rstd = 1.0f / sqrtf(fmaf(half_sum(ss), inv_d, eps));
+        const int row = row0 + 2 * r + half;
+        if (hl == 0 && row < rows) stats[row] = make_float2(mean * rstd, rstd);
     }
 }
 
@@ -261,13 +269,13 @@ int launch_layernorm(const void* x, const float* g, const float* b, void* y, int
 }
 
 int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, float eps, int dtype, hipStream_t stream) {
-    VIT_REQUIRE(rows > 0 && dim > 0 && dim % 4 == 0 && xs % 4 == 0 && dim <= 2048, "ln_stats: bad shape rows=%d dim=%d", rows, dim);
+    VIT_REQUIRE(rows > 0 && dim > 0 && dim % 8 == 0 && xs % 8 == 0 && dim <= 2048, "ln_stats: bad shape rows=%d dim=%d (multiples of 8)", rows, dim);
     VIT_REQUIRE(dtype == VIT_BF16, "ln_stats: bf16 only");
-    const int blocks = ceil_div(rows, 16);  // 4 waves x 4 rows: one step per wave, no grid-stride tail
+    const int blocks = ceil_div(rows, 32);  // 4 waves x 4 row pairs, one step per wave
     const bf16_t* xp = (const bf16_t*)x;
     float2* sp = (float2*)stats;
 #define VIT_LN_STATS_CASE(NIT) \
-    case NIT: hipLaunchKernelGGL((ln_stats_kernel<bf16_t, NIT>), dim3(blocks), dim3(256), 0, stream, xp, sp, rows, dim, xs, eps); break;
+    case NIT: hipLaunchKernelGGL((ln_stats_kernel<NIT>), dim3(blocks), dim3(256), 0, stream, xp, sp, rows, dim, xs, eps); break;
     switch (ceil_div(dim, 256)) {
         VIT_LN_STATS_CASE(1) VIT_LN_STATS_CASE(2) VIT_LN_STATS_CASE(3) VIT_LN_STATS_CASE(4)
         VIT_LN_STATS_CASE(5) VIT_LN_STATS_CASE(6) VIT_LN_STATS_CASE(7) VIT_LN_STATS_CASE(8)
