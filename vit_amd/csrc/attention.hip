@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512) void attention_bf16_kernel(const bf16_t* __res
             float mx = s[0];
 #pragma unroll
             for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = max_across_halves(mx);
             const float m_new = fmaxf(m_run, mx * scale_log2e);
             // the running max rarely moves after the first tiles: rescale O / l only when some
             // query of the wave saw a larger score (wave-uniform branch; exact, no threshold)

@@ -65,13 +65,6 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
 
 typedef int int4v __attribute__((ext_vector_type(4)));
 
-// max over the two lane halves (lane l and lane l ^ 32) without the LDS round trip of a shuffle
-__device__ __forceinline__ float max_across_halves(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-}
-
 template <bool LSE>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_dh64_kernel(
     const AttnSrc src, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H, int nitems, int qblocks,

@@ -112,6 +112,13 @@ __device__ __forceinline__ float apply_act(float v) {
     return v;
 }
 
+// max over the two lane halves (lane l and lane l ^ 32) without the LDS round trip of a shuffle
+__device__ __forceinline__ float max_across_halves(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+}
+
 // wave-wide sum over 64 lanes
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
