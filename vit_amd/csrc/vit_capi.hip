@@ -327,13 +327,15 @@ Workspace plan_workspace(const vit_ctx* ctx, int batch) {
 }
 }  // namespace
 
-// A batch is cut into up to ctx->nstreams contiguous chunks of at least kMinChunk images, one stream each
-static const int kMinChunk = 32;
-static int num_chunks(const vit_ctx* ctx, int batch) {
+// A batch is cut into up to ctx->nstreams contiguous chunks of at least kMinChunkRows token rows (32 images of
+// 197 tokens: below that a chunk's GEMMs are too few tiles to be worth a stream), one stream each
+int vit_num_chunks(const vit_ctx* ctx, int batch) {
+    static const long kMinChunkRows = 32 * 197;
     int k = ctx->nstreams;
-    while (k > 1 && batch / k < kMinChunk) --k;
+    while (k > 1 && (long)(batch / k) * ctx->N < kMinChunkRows) --k;
     return k;
 }
+static int num_chunks(const vit_ctx* ctx, int batch) { return vit_num_chunks(ctx, batch); }
 static int chunk_begin(int batch, int k, int i) { return (int)((long)batch * i / k); }
 
 extern "C" size_t vit_workspace_bytes(const vit_ctx* ctx, int batch) {

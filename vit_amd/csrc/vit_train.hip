@@ -21,6 +21,7 @@ int launch_convert_2d(const void* src, int sdt, void* dst, int ddt, int64_t rows
                       hipStream_t stream);
 
 extern "C" int vit_train_refresh_transposes(vit_ctx* ctx, void* stream_);
+int vit_num_chunks(const vit_ctx* ctx, int batch);  // vit_capi.hip: the stream split rule of vit_forward
 
 struct TrainState {
     float* master = nullptr;        // fp32 master copy of every parameter, gradient-arena layout
@@ -335,7 +336,7 @@ extern "C" int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel
 
     // as vit_forward: two halves on two streams, so one half's kernels fill the CUs the other half's last
     // round of GEMM tiles leaves idle (the stash keeps its single-batch layout)
-    const int k = (ctx->nstreams >= 2 && batch >= 64) ? 2 : 1;
+    const int k = vit_num_chunks(ctx, batch) >= 2 ? 2 : 1;
     if (k == 1) return run(0, batch, stream);
     const int h0 = (batch + 1) / 2;
     VIT_CHECK_HIP(hipEventRecord(ctx->ev_fork, stream));
