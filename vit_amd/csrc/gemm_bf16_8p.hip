@@ -96,7 +96,8 @@ struct PParams {
     unsigned long long* stamps;  // lab only: 8 x s_memrealtime per workgroup around its second tile
 };
 
-constexpr int EPI_PATCH = 100;  // internal: bias + position add + row remap past the CLS slot, A from pixels
+constexpr int EPI_PATCH = 100;        // internal: bias + position add + row remap past the CLS slot, A from pixels
+constexpr int EPI_PATCH_DENSE = 101;  // the same epilogue on a dense A (rows = patches already gathered, any patch size)
 
 // EPI: VIT_EPI_* or EPI_PATCH; for VIT_EPI_DGELU / VIT_EPI_DQUICK_GELU `res` is the pre-activation the
 // gradient is multiplied with. OUTM: 0 = bf16 C, 1 = fp32 C (weight gradients), 2 = bf16 C plus
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             const int nb = n0 + wc * 64 + 4 * i;
             const bool col_ok = nb < P.N;  // N % 8 == 0: 4 columns all in or all out
             const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
-            if constexpr (EPI == EPI_PATCH) {
+            if constexpr (EPI == EPI_PATCH || EPI == EPI_PATCH_DENSE) {
                 // GEMM row g = b * np + patch goes to output row g + b + 1 (one CLS slot per image) and gets
                 // position row 1 + patch. The tile's rows lie in at most 5 images (np >= 64, host check):
                 // b - b0 = number of image starts e1, e1 + np, ... at or below the local row.
@@ -620,4 +621,33 @@ int launch_gemm_bf16_8p_patch(const void* pixels, const void* W, const float* bi
     q.stamps = g8_stamps;
 #endif
     return g8::launch_persist<g8::EPI_PATCH, 0>(q, ncu, stream);
+}
+
+// The same epilogue on an already gathered patch matrix A [M, K] (bf16, K a legal K of this kernel, zero
+// padded): the route for patch sizes whose pixel rows are not 16-byte pieces (P = 14).
+bool gemm_bf16_8p_patch_dense_eligible(int M, int N, int K, const PatchGeom* g) {
+    return gemm_bf16_8p_eligible(M, N, K) && g->grid * g->grid >= 64 && M % (g->grid * g->grid) == 0 &&
+           (size_t)(g->grid * g->grid + 1) * N * 4 < ((size_t)1 << 32) && (long)M * N >= 64L * 256 * 256;
+}
+int launch_gemm_bf16_8p_patch_dense(const void* A, const void* W, const float* bias, const float* pos, void* C, int M, int N,
+                                    int K, const PatchGeom* g, hipStream_t stream) {
+    VIT_REQUIRE(gemm_bf16_8p_patch_dense_eligible(M, N, K, g), "gemm8p: dense patch problem not eligible");
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        VIT_CHECK_HIP(hipGetDevice(&dev));
+        VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    g8::PParams q{};
+    q.A = (const bf16_t*)A; q.W = (const bf16_t*)W; q.bias = bias; q.C = (bf16_t*)C; q.pos = pos;
+    q.M = M; q.N = N; q.K = K; q.lda = K;
+    q.NT = ceil_div(N, g8::BN);
+    q.TMN = ceil_div(M, g8::BM) * q.NT;
+    q.T = q.TMN;
+    q.np = g->grid * g->grid; q.grid = g->grid; q.patch = g->patch; q.image = g->image;
+#ifdef G8_LAB
+    q.dbg = g8_dbg;
+    q.stamps = g8_stamps;
+#endif
+    return g8::launch_persist<g8::EPI_PATCH_DENSE, 0>(q, ncu, stream);
 }

@@ -257,7 +257,46 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__
     }
 }
 
+// ---- patch rows: A[b * np + py * grid + px][c * P * P + i * P + j] = pixels[b, c, py * P + i, px * P + j], columns
+// >= C * P * P zero (the Conv2d-as-GEMM operand, modeling_vit.py:62-69, written out for patch sizes whose pixel rows
+// are not 16-byte pieces). One thread per 8 output columns: 16-byte stores along k.
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const bf16_t* __restrict__ pix, bf16_t* __restrict__ A, long rows,
+                                                          int kp, PatchGeom g) {
+    const int kchunks = kp >> 3;
+    const long total = rows * kchunks;
+    const int np = g.grid * g.grid, pp = g.patch * g.patch;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / kchunks;
+        const int k0 = (int)(idx - row * kchunks) << 3;
+        const int b = (int)(row / np), rem = (int)(row - (long)b * np);
+        const int py = rem / g.grid, px = rem - py * g.grid;
+        const bf16_t* src = pix + ((size_t)b * g.channels * g.image + (size_t)py * g.patch) * g.image + (size_t)px * g.patch;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            if (k < g.kreal) {
+                const int c = k / pp, r2 = k - c * pp;
+                const int i = r2 / g.patch, j = r2 - i * g.patch;
+                v[e] = src[((size_t)c * g.image + i) * g.image + j];
+            } else {
+                v[e] = (bf16_t)0.0f;
+            }
+        }
+        *(bf16x8*)(A + row * kp + k0) = v;
+    }
+}
+
 }  // namespace
+
+int launch_im2col_rows(const void* pixels, void* A, long rows, int kp, const PatchGeom* g, hipStream_t stream) {
+    VIT_REQUIRE(rows > 0 && kp % 8 == 0 && kp >= g->kreal, "im2col_rows: bad shape");
+    long blocks = (rows * (kp >> 3) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(im2col_rows_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)pixels, (bf16_t*)A, rows, kp, *g);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
 
 int launch_layernorm(const void* x, const float* g, const float* b, void* y, int rows, int dim, int64_t xs, int64_t ys,
                      float eps, int dtype, hipStream_t stream) {

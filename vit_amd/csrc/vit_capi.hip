@@ -211,29 +211,46 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
         w.wqkv = A + lo[l].wqkv; w.wo = A + lo[l].wo; w.w1 = A + lo[l].w1; w.w2 = A + lo[l].w2;
     }
     ctx->n_missing = (int)ctx->slots.size();
-    // LayerNorm folded into the QKV / fc1 GEMMs (bf16 contexts). The folded copies live in their own arena,
+    // LayerNorm folded into the QKV / fc1 GEMMs (bf16 contexts), and a 128-padded copy of the patch weight for
+    // patch sizes the persistent kernel's pixel loader does not take. The copies live in their own arena,
     // allocated here so that no forward ever allocates.
     ctx->fold_arena = nullptr;
     ctx->fold_dirty = true;
+    ctx->patch_kp = 0;
+    ctx->patch_w_kp = nullptr;
     const char* fl = getenv("VIT_AMD_FUSE_LN");
     ctx->ln_fuse = (T == VIT_BF16 && !(fl && atoi(fl) == 0)) ? 1 : 0;
-    if (ctx->ln_fuse) {
-        const size_t per = align256((size_t)3 * D * D * 2) + align256((size_t)F * D * 2) + 2 * align256((size_t)3 * D * 4) +
-                           2 * align256((size_t)F * 4);
-        e = hipMalloc((void**)&ctx->fold_arena, per * L);
+    if (T == VIT_BF16) {
+        PatchGeom pg0{c.num_channels, c.image_size, c.patch_size, g, ctx->kreal};
+        const int np0 = g * g;
+        if (!gemm_bf16_8p_patch_eligible(np0 * 64, D, &pg0) && np0 >= 64 && D % 8 == 0) ctx->patch_kp = (ctx->kreal + 127) / 128 * 128;
+        if (ctx->patch_kp < 256) ctx->patch_kp = 0;
+    }
+    if (ctx->ln_fuse || ctx->patch_kp) {
+        const size_t per = ctx->ln_fuse ? align256((size_t)3 * D * D * 2) + align256((size_t)F * D * 2) + 2 * align256((size_t)3 * D * 4) +
+                                              2 * align256((size_t)F * 4)
+                                        : 0;
+        const size_t pw = ctx->patch_kp ? align256((size_t)D * ctx->patch_kp * 2) : 0;
+        e = hipMalloc((void**)&ctx->fold_arena, per * L + pw);
+        if (e == hipSuccess && pw) e = hipMemset(ctx->fold_arena, 0, pw);  // the K padding stays zero
+        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) {
             (void)hipFree(ctx->arena);
+            if (ctx->fold_arena) (void)hipFree(ctx->fold_arena);
             delete ctx;
-            return vit_set_error(VIT_E_NOMEM, "vit_create: hipMalloc(%zu) for the folded weights failed: %s", per * L, hipGetErrorString(e));
+            return vit_set_error(VIT_E_NOMEM, "vit_create: hipMalloc(%zu) for the folded weights failed: %s", per * L + pw, hipGetErrorString(e));
         }
-        ctx->folds.resize(L);
         unsigned char* p = ctx->fold_arena;
         auto take = [&](size_t bytes) { unsigned char* r = p; p += align256(bytes); return r; };
-        for (int l = 0; l < L; ++l) {
-            LnFold& f = ctx->folds[l];
-            f.wqkv = take((size_t)3 * D * D * 2); f.w1 = take((size_t)F * D * 2);
-            f.cqkv = (float*)take((size_t)3 * D * 4); f.dqkv = (float*)take((size_t)3 * D * 4);
-            f.c1 = (float*)take((size_t)F * 4); f.d1 = (float*)take((size_t)F * 4);
+        if (pw) ctx->patch_w_kp = take((size_t)D * ctx->patch_kp * 2);
+        if (ctx->ln_fuse) {
+            ctx->folds.resize(L);
+            for (int l = 0; l < L; ++l) {
+                LnFold& f = ctx->folds[l];
+                f.wqkv = take((size_t)3 * D * D * 2); f.w1 = take((size_t)F * D * 2);
+                f.cqkv = (float*)take((size_t)3 * D * 4); f.dqkv = (float*)take((size_t)3 * D * 4);
+                f.c1 = (float*)take((size_t)F * 4); f.d1 = (float*)take((size_t)F * 4);
+            }
         }
     }
     // two-stream forward: on by default for bf16 contexts, VIT_AMD_DUAL_STREAM=0/1 overrides
@@ -307,7 +324,7 @@ extern "C" int vit_missing_weights(vit_ctx* ctx, const char** first_missing) {
 // ---------------------------------------------------------------- forward
 namespace {
 struct Workspace {
-    size_t x, ln, qkv, ctxv, h, pix, stats, total;
+    size_t x, ln, qkv, ctxv, h, pix, stats, rows, total;
 };
 Workspace plan_workspace(const vit_ctx* ctx, int batch) {
     const vit_config& c = ctx->cfg;
@@ -322,6 +339,7 @@ Workspace plan_workspace(const vit_ctx* ctx, int batch) {
     w.h = take(M * c.intermediate_size * es);
     w.pix = take((size_t)batch * c.num_channels * c.image_size * c.image_size * es);
     w.stats = take(M * 8);  // folded LayerNorm: (mean * rstd, rstd) per row
+    w.rows = take(ctx->patch_kp ? (size_t)batch * (ctx->N - 1) * ctx->patch_kp * 2 : 0);  // gathered patch rows
     w.total = cur;
     return w;
 }
@@ -360,9 +378,12 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
 // written or read: a statistics pass over x (8 bytes out per row) replaces the LayerNorm kernel. The folded
 // copies are rebuilt on the forward's stream after any weight change (load, SGD step).
 static int refresh_folds(vit_ctx* ctx, hipStream_t stream) {
-    if (!ctx->ln_fuse || !ctx->fold_dirty) return VIT_OK;
+    if (!ctx->fold_dirty || (!ctx->ln_fuse && !ctx->patch_kp)) return VIT_OK;
     const int D = ctx->cfg.hidden_size, F = ctx->cfg.intermediate_size;
-    for (int l = 0; l < ctx->cfg.num_hidden_layers; ++l) {
+    if (ctx->patch_kp)  // [D, kreal] out of the [D, kpad] arena copy into the 128-padded one
+        VIT_CHECK_HIP(hipMemcpy2DAsync(ctx->patch_w_kp, (size_t)ctx->patch_kp * 2, ctx->patch_w, (size_t)ctx->kpad * 2,
+                                       (size_t)ctx->kreal * 2, D, hipMemcpyDeviceToDevice, stream));
+    for (int l = 0; ctx->ln_fuse && l < ctx->cfg.num_hidden_layers; ++l) {
         const LayerW& lw = ctx->layers[l];
         const LnFold& f = ctx->folds[l];
         VIT_TRY(launch_ln_fold(lw.wqkv, D, lw.ln1_g, lw.ln1_b, lw.bqkv, f.wqkv, f.cqkv, f.dqkv, 3 * D, D, stream));
@@ -447,8 +468,15 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
     }
     VIT_TRY(launch_cls_rows(ctx->cls, ctx->pos, x, batch, N, D, T, stream));
     PatchGeom pg{c.num_channels, c.image_size, c.patch_size, c.image_size / c.patch_size, ctx->kreal};
-    VIT_TRY(launch_gemm(pix, ctx->patch_w, ctx->patch_b, nullptr, x, batch * (N - 1), D, ctx->kpad, VIT_EPI_BIAS, T, &pg,
-                        ctx->pos, stream));
+    const int Mp = batch * (N - 1);
+    if (ctx->patch_kp && !ctx->fold_dirty && gemm_bf16_8p_patch_dense_eligible(Mp, D, ctx->patch_kp, &pg)) {
+        // P = 14 and the like: gather the patch rows once (16-byte stores), then the persistent GEMM with the
+        // CLS-slot / position epilogue; the generic kernel's element gather is 6x slower at CLIP-L/14-336
+        VIT_TRY(launch_im2col_rows(pix, ws + w.rows, Mp, ctx->patch_kp, &pg, stream));
+        VIT_TRY(launch_gemm_bf16_8p_patch_dense(ws + w.rows, ctx->patch_w_kp, ctx->patch_b, ctx->pos, x, Mp, D, ctx->patch_kp, &pg, stream));
+    } else {
+        VIT_TRY(launch_gemm(pix, ctx->patch_w, ctx->patch_b, nullptr, x, Mp, D, ctx->kpad, VIT_EPI_BIAS, T, &pg, ctx->pos, stream));
+    }
     if (clip) VIT_TRY(launch_layernorm(x, ctx->pre_g, ctx->pre_b, x, M, D, D, D, c.layer_norm_eps, T, stream));
 
     for (int l = 0; l < c.num_hidden_layers; ++l) {

@@ -169,6 +169,13 @@ int launch_layernorm_bwd(const void* x, const void* dy, const float* gamma, cons
 constexpr int kLnBwdMaxBlocks = 2048;
 int launch_embed_grad(const void* dx0, float* dpos, float* dcls, int B, int N, int D, hipStream_t stream);
 int launch_sgd(float* master, const float* grad, void* copy_bf16, float lr, int64_t n, hipStream_t stream);
+// patch rows gathered into a dense bf16 matrix [rows, kp] (layernorm.hip) and the patch-embedding GEMM on it
+// (gemm_bf16_8p.hip): the route for patch sizes the pixel loader of the persistent kernel does not take
+int launch_im2col_rows(const void* pixels, void* A, long rows, int kp, const PatchGeom* g, hipStream_t stream);
+bool gemm_bf16_8p_patch_eligible(int M, int N, const PatchGeom* g);
+bool gemm_bf16_8p_patch_dense_eligible(int M, int N, int K, const PatchGeom* g);
+int launch_gemm_bf16_8p_patch_dense(const void* A, const void* W, const float* bias, const float* pos, void* C, int M, int N,
+                                    int K, const PatchGeom* g, hipStream_t stream);
 // LayerNorm folded into the next GEMM (layernorm.hip): per-row (mean * rstd, rstd), and the weight fold
 int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, float eps, int dtype, hipStream_t stream);
 int launch_ln_fold(const void* W, int64_t pitch, const float* gamma, const float* beta, const float* bias, void* Wg, float* c,

@@ -64,7 +64,11 @@ struct vit_ctx {
     hipEvent_t ev_fork, ev_join[kMaxStreams - 1];
     int nstreams;  // 1 = single stream
     // folded LayerNorm (vit_capi.hip): copies are refreshed on the forward's stream whenever a weight changed
-    int ln_fuse;               // 0 = off (fp32 contexts, D not a legal K of the persistent GEMM, VIT_AMD_FUSE_LN=0)
+    int ln_fuse;               // 0 = off (fp32 contexts, VIT_AMD_FUSE_LN=0)
+    // patch sizes the persistent GEMM's pixel loader does not take (P = 14): the forward gathers the patch rows
+    // into a dense [B * np, patch_kp] matrix and multiplies by a copy of the patch weight padded to patch_kp
+    int patch_kp;              // 0 = route not used; else C*P*P rounded up to a multiple of 128
+    void* patch_w_kp;          // [D, patch_kp] bf16, zero padded (in fold_arena, refreshed with the folds)
     unsigned char* fold_arena;
     std::vector<LnFold> folds;
     bool fold_dirty;
