@@ -254,16 +254,17 @@ def test_folded_layernorm_matches_unfolded_and_oracle(monkeypatch, variant):
 
 
 @pytest.mark.gpu
-def test_patch14_dense_route_matches_oracle_and_small_batches():
+@pytest.mark.parametrize("image,batch", [(112, 256), (126, 208)])  # 64 patches (tile-aligned seams) / 81 (ragged)
+def test_patch14_dense_route_matches_oracle_and_small_batches(image, batch):
     """Patch sizes whose pixel rows are not 16-byte pieces (P = 14): big batches gather the patch rows into a dense
     matrix and run the persistent GEMM on it (vit_capi.hip forward_range), small ones use the generic kernel's
     gather loader. Same bits for the same image, and both match the oracle."""
     cfg = ViTConfig(variant="clip", hidden_act="quick_gelu", layer_norm_eps=1e-5, hidden_size=256, num_hidden_layers=1,
-                    num_attention_heads=4, intermediate_size=512, image_size=112, patch_size=14)
+                    num_attention_heads=4, intermediate_size=512, image_size=image, patch_size=14)
     sd = vit_oracle.quantize_state_dict_bf16(synth.synthetic_state_dict(cfg, seed=0))
     enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
     enc.load_state_dict(sd)
-    px = synth.synthetic_images(cfg, 256, seed=4).to(torch.bfloat16)   # 256 * 64 patch rows x 256: persistent kernel
+    px = synth.synthetic_images(cfg, batch, seed=4).to(torch.bfloat16)  # >= 16384 patch rows x 256: persistent kernel
     out = enc(px)
     sub = enc(px[17:23])                                                # generic kernel
     assert torch.equal(sub.last_hidden_state, out.last_hidden_state[17:23])
