@@ -334,6 +334,40 @@ int launch_im2col_t(const void* pixels, int pixel_dtype, void* dst, int R, int R
     return VIT_OK;
 }
 
+// fp32 master arena -> the bf16 / fp32 weight arena, every tensor in ONE launch: block (s, j) takes a stride of
+// slot s (a training step used to issue one small convert per tensor, ~150 launches of a few microseconds)
+__global__ __launch_bounds__(256) void multi_convert_kernel(const float* __restrict__ master, unsigned char* __restrict__ arena,
+                                                            const ConvSlot* __restrict__ tab) {
+    const ConvSlot s = tab[blockIdx.x];
+    const float* src = master + s.src;
+    const long long stride = (long long)gridDim.y * 256;
+    if (s.vec4) {
+        for (long long i = ((long long)blockIdx.y * 256 + threadIdx.x) * 4; i < s.n; i += stride * 4) {
+            const f32x4 v = *(const f32x4*)(src + i);
+            if (s.dtype == VIT_BF16) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                *(bf16x4*)(arena + s.dst + i * 2) = o;
+            } else {
+                *(f32x4*)(arena + s.dst + i * 4) = v;
+            }
+        }
+    } else {
+        for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < s.n; i += stride) {
+            if (s.dtype == VIT_BF16) ((bf16_t*)(arena + s.dst))[i] = (bf16_t)src[i];
+            else ((float*)(arena + s.dst))[i] = src[i];
+        }
+    }
+}
+
+int launch_multi_convert(const float* master, void* arena, const ConvSlot* table_dev, int nslots, hipStream_t stream) {
+    if (nslots <= 0) return VIT_OK;
+    hipLaunchKernelGGL(multi_convert_kernel, dim3(nslots, 32), dim3(256), 0, stream, master, (unsigned char*)arena, table_dev);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
 int launch_sgd(float* master, const float* grad, void* copy_bf16, float lr, int64_t n, hipStream_t stream) {
     if (n <= 0) return VIT_OK;
     const int64_t blocks = (n / 4 + 256) / 256;

@@ -169,6 +169,13 @@ int launch_layernorm_bwd(const void* x, const void* dy, const float* gamma, cons
 constexpr int kLnBwdMaxBlocks = 2048;
 int launch_embed_grad(const void* dx0, float* dpos, float* dcls, int B, int N, int D, hipStream_t stream);
 int launch_sgd(float* master, const float* grad, void* copy_bf16, float lr, int64_t n, hipStream_t stream);
+// one slot of launch_multi_convert (train_ops.hip): n contiguous elements of the fp32 master arena at element
+// offset src go to byte offset dst of the weight arena as dtype
+struct ConvSlot {
+    long long src, dst, n;
+    int dtype, vec4;  // vec4: offsets and length allow 4-element accesses
+};
+int launch_multi_convert(const float* master, void* arena, const ConvSlot* table_dev, int nslots, hipStream_t stream);
 // patch rows gathered into a dense bf16 matrix [rows, kp] (layernorm.hip) and the patch-embedding GEMM on it
 // (gemm_bf16_8p.hip): the route for patch sizes the pixel loader of the persistent kernel does not take
 int launch_im2col_rows(const void* pixels, void* A, long rows, int kp, const PatchGeom* g, hipStream_t stream);

@@ -29,6 +29,8 @@ struct TrainState {
     size_t wt_bytes = 0;
     struct LayerT { void *wqkvT, *woT, *w1T, *w2T; };
     std::vector<LayerT> layers;
+    ConvSlot* conv_table = nullptr;  // device: every parameter tensor, master arena -> weight arena (vit_sgd_step)
+    int nconv = 0;
 };
 
 int launch_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* db, float* slabs, int T, int Mo, int No,
@@ -174,6 +176,7 @@ void vit_train_free(vit_ctx* ctx) {
     if (!ctx || !ctx->train) return;
     if (ctx->train->master) (void)hipFree(ctx->train->master);
     if (ctx->train->wt) (void)hipFree(ctx->train->wt);
+    if (ctx->train->conv_table) (void)hipFree(ctx->train->conv_table);
     delete ctx->train;
     ctx->train = nullptr;
 }
@@ -232,6 +235,23 @@ extern "C" int vit_train_init(vit_ctx* ctx, void* stream_) {
             t->layers[l].woT = t->wt + cur;   cur += align256(D * D * 2);
             t->layers[l].w1T = t->wt + cur;   cur += align256(D * F * 2);
             t->layers[l].w2T = t->wt + cur;   cur += align256(D * F * 2);
+        }
+        std::vector<ConvSlot> tab;
+        for (auto& kv : ctx->slots) {
+            const Slot& s = kv.second;
+            const long long n = (long long)s.rows * s.pitch;
+            const size_t es = esize(s.dtype);
+            tab.push_back(ConvSlot{(long long)s.goff, (long long)s.offset, n, s.dtype,
+                                   (s.goff % 4 == 0 && s.offset % (4 * es) == 0 && n % 4 == 0) ? 1 : 0});
+        }
+        t->nconv = (int)tab.size();
+        e = hipMalloc((void**)&t->conv_table, tab.size() * sizeof(ConvSlot));
+        if (e == hipSuccess) e = hipMemcpy(t->conv_table, tab.data(), tab.size() * sizeof(ConvSlot), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(t->master); (void)hipFree(t->wt);
+            if (t->conv_table) (void)hipFree(t->conv_table);
+            delete t;
+            return vit_set_error(VIT_E_NOMEM, "vit_train_init: slot table upload failed: %s", hipGetErrorString(e));
         }
         ctx->train = t;
     }
@@ -459,10 +479,6 @@ extern "C" int vit_sgd_step(vit_ctx* ctx, const void* grads_, float lr, void* st
     hipStream_t stream = (hipStream_t)stream_;
     VIT_TRY(launch_sgd(ctx->train->master, (const float*)grads_, nullptr, lr, (int64_t)ctx->g_total, stream));
     ctx->fold_dirty = true;  // the inference forward's folded LayerNorm copies are stale now
-    for (auto& kv : ctx->slots) {
-        const Slot& s = kv.second;
-        VIT_TRY(launch_convert_2d(ctx->train->master + s.goff, VIT_F32, ctx->arena + s.offset, s.dtype, s.rows, s.pitch,
-                                  s.pitch, stream));
-    }
+    VIT_TRY(launch_multi_convert(ctx->train->master, ctx->arena, ctx->train->conv_table, ctx->train->nconv, stream));
     return vit_train_refresh_transposes(ctx, stream_);
 }
