@@ -15,11 +15,11 @@ namespace {
 // rows of [B, N, D] without the CLS rows). dst: [C, Rpad] bf16, columns R..Rpad zero.
 // colsum (optional): fp32 [C], += sum over r of src[r, c] (pre-zeroed by the caller).
 constexpr int TT = 64;
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                                            float* __restrict__ colsum, int R, int C, int Rpad,
-                                                            int group) {
+__device__ __forceinline__ void transpose_pad_tile(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                   float* __restrict__ colsum, int R, int C, int Rpad, int group, int bx,
+                                                   int by) {
     __shared__ unsigned short tile[TT][TT + 2];
-    const int r0 = blockIdx.x * TT, c0 = blockIdx.y * TT;
+    const int r0 = bx * TT, c0 = by * TT;
     const int tid = threadIdx.x;
     // load: 64 rows x 64 cols, 8 bf16 per thread per pass, 2 passes
 #pragma unroll
@@ -60,6 +60,25 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __rest
         part += __shfl_xor(part, 2, 64);
         if ((tid & 3) == 0 && c < C) atomicAdd(colsum + c, part);
     }
+}
+
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                            float* __restrict__ colsum, int R, int C, int Rpad,
+                                                            int group) {
+    transpose_pad_tile(src, dst, colsum, R, C, Rpad, group, blockIdx.x, blockIdx.y);
+}
+
+// Several plain transposes ([R, C] -> [C, R], R % 8 == 0) in one launch: block b belongs to the table entry whose
+// [first_block, first_block + tiles) range holds it (a training step refreshes 4 transposed weights per layer).
+__global__ __launch_bounds__(256) void multi_transpose_kernel(const TransposeSlot* __restrict__ tab, int n) {
+    int i = 0, hi = n - 1;  // uniform binary search (scalar loads): last entry with first_block <= blockIdx.x
+    while (i < hi) {
+        const int mid = (i + hi + 1) >> 1;
+        if ((int)blockIdx.x >= tab[mid].first_block) i = mid; else hi = mid - 1;
+    }
+    const TransposeSlot t = tab[i];
+    const int local = blockIdx.x - t.first_block, tx = (t.R + TT - 1) / TT;
+    transpose_pad_tile((const bf16_t*)t.src, (bf16_t*)t.dst, nullptr, t.R, t.C, t.R, 0, local % tx, local / tx);
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -283,6 +302,13 @@ int launch_transpose_pad(const void* src, void* dst, float* colsum, int R, int C
     dim3 grid(ceil_div(Rpad, TT), ceil_div(C, TT));
     hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, colsum, R, C,
                        Rpad, group);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+int launch_multi_transpose(const TransposeSlot* table_dev, int n, int total_blocks, hipStream_t stream) {
+    if (n <= 0) return VIT_OK;
+    hipLaunchKernelGGL(multi_transpose_kernel, dim3(total_blocks), dim3(256), 0, stream, table_dev, n);
     VIT_CHECK_HIP(hipGetLastError());
     return VIT_OK;
 }

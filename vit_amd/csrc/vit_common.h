@@ -175,6 +175,14 @@ struct ConvSlot {
     long long src, dst, n;
     int dtype, vec4;  // vec4: offsets and length allow 4-element accesses
 };
+// one entry of launch_multi_transpose (train_ops.hip): src [R, C] bf16 -> dst [C, R]; blocks
+// [first_block, first_block + ceil(R/64) * ceil(C/64)) of the launch belong to it
+struct TransposeSlot {
+    const void* src;
+    void* dst;
+    int R, C, first_block, pad;
+};
+int launch_multi_transpose(const TransposeSlot* table_dev, int n, int total_blocks, hipStream_t stream);
 int launch_multi_convert(const float* master, void* arena, const ConvSlot* table_dev, int nslots, hipStream_t stream);
 // patch rows gathered into a dense bf16 matrix [rows, kp] (layernorm.hip) and the patch-embedding GEMM on it
 // (gemm_bf16_8p.hip): the route for patch sizes the pixel loader of the persistent kernel does not take

@@ -31,6 +31,8 @@ struct TrainState {
     std::vector<LayerT> layers;
     ConvSlot* conv_table = nullptr;  // device: every parameter tensor, master arena -> weight arena (vit_sgd_step)
     int nconv = 0;
+    TransposeSlot* tr_table = nullptr;  // device: the 4 transposed weights of every layer (vit_train_refresh_transposes)
+    int ntr = 0, tr_blocks = 0;
 };
 
 int launch_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* db, float* slabs, int T, int Mo, int No,
@@ -177,6 +179,7 @@ void vit_train_free(vit_ctx* ctx) {
     if (ctx->train->master) (void)hipFree(ctx->train->master);
     if (ctx->train->wt) (void)hipFree(ctx->train->wt);
     if (ctx->train->conv_table) (void)hipFree(ctx->train->conv_table);
+    if (ctx->train->tr_table) (void)hipFree(ctx->train->tr_table);
     delete ctx->train;
     ctx->train = nullptr;
 }
@@ -253,6 +256,29 @@ extern "C" int vit_train_init(vit_ctx* ctx, void* stream_) {
             delete t;
             return vit_set_error(VIT_E_NOMEM, "vit_train_init: slot table upload failed: %s", hipGetErrorString(e));
         }
+        std::vector<TransposeSlot> tt;
+        int fb = 0;
+        auto add_tr = [&](const void* src, void* dst, int R, int C) {
+            tt.push_back(TransposeSlot{src, dst, R, C, fb, 0});
+            fb += ceil_div(R, 64) * ceil_div(C, 64);
+        };
+        for (int l = 0; l < c.num_hidden_layers; ++l) {
+            const LayerW& w = ctx->layers[l];
+            add_tr(w.wqkv, t->layers[l].wqkvT, 3 * (int)D, (int)D);  // [3D,D] -> [D,3D]
+            add_tr(w.wo, t->layers[l].woT, (int)D, (int)D);
+            add_tr(w.w1, t->layers[l].w1T, (int)F, (int)D);          // [F,D] -> [D,F]
+            add_tr(w.w2, t->layers[l].w2T, (int)D, (int)F);          // [D,F] -> [F,D]
+        }
+        t->ntr = (int)tt.size();
+        t->tr_blocks = fb;
+        e = hipMalloc((void**)&t->tr_table, tt.size() * sizeof(TransposeSlot));
+        if (e == hipSuccess) e = hipMemcpy(t->tr_table, tt.data(), tt.size() * sizeof(TransposeSlot), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(t->master); (void)hipFree(t->wt); (void)hipFree(t->conv_table);
+            if (t->tr_table) (void)hipFree(t->tr_table);
+            delete t;
+            return vit_set_error(VIT_E_NOMEM, "vit_train_init: transpose table upload failed: %s", hipGetErrorString(e));
+        }
         ctx->train = t;
     }
     VIT_CHECK_HIP(hipMemsetAsync(ctx->train->master, 0, ctx->g_total * 4, stream));
@@ -267,17 +293,8 @@ extern "C" int vit_train_init(vit_ctx* ctx, void* stream_) {
 // (re)build W^T for the data-gradient GEMMs from the current bf16 weights
 extern "C" int vit_train_refresh_transposes(vit_ctx* ctx, void* stream_) {
     VIT_REQUIRE(ctx && ctx->train, "vit_train_refresh_transposes: call vit_train_init first");
-    hipStream_t stream = (hipStream_t)stream_;
-    const int D = ctx->cfg.hidden_size, F = ctx->cfg.intermediate_size;
-    for (int l = 0; l < ctx->cfg.num_hidden_layers; ++l) {
-        const LayerW& w = ctx->layers[l];
-        const TrainState::LayerT& t = ctx->train->layers[l];
-        VIT_TRY(launch_transpose_pad(w.wqkv, t.wqkvT, nullptr, 3 * D, D, 3 * D, 0, stream));  // [3D,D] -> [D,3D]
-        VIT_TRY(launch_transpose_pad(w.wo, t.woT, nullptr, D, D, D, 0, stream));
-        VIT_TRY(launch_transpose_pad(w.w1, t.w1T, nullptr, F, D, F, 0, stream));              // [F,D] -> [D,F]
-        VIT_TRY(launch_transpose_pad(w.w2, t.w2T, nullptr, D, F, D, 0, stream));              // [D,F] -> [F,D]
-    }
-    return VIT_OK;
+    // D and F are multiples of 8 (vit_create), so the transposes need no row padding: one launch for all of them
+    return launch_multi_transpose(ctx->train->tr_table, ctx->train->ntr, ctx->train->tr_blocks, (hipStream_t)stream_);
 }
 
 // ---------------------------------------------------------------- forward that stashes
