@@ -231,6 +231,29 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
 template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
                                                          float* __restrict__ delta, int B, int N, int H) {
+    constexpr int CPH = DH / 8;  // 16-byte chunks per head
+    if constexpr ((CPH & (CPH - 1)) == 0 && CPH <= 16) {
+        // one lane per 16-byte chunk: a wave instruction reads 1 KiB of consecutive memory; the CPH lanes of a
+        // (row, head) sum their products by a butterfly (CPH is a power of two and divides 64)
+        const long f = (long)blockIdx.x * 256 + threadIdx.x;  // chunk index over B * N * H * CPH
+        const long total = (long)B * N * H * CPH;
+        float s = 0.f;
+        if (f < total) {
+            const bf16x8 a = *(const bf16x8*)(O + f * 8), bb = *(const bf16x8*)(dO + f * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)bb[e];
+        }
+#pragma unroll
+        for (int o = CPH >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (f < total && (threadIdx.x & (CPH - 1)) == 0) {
+            const long idx = f / CPH;                      // (row, head), head fastest
+            const int h = (int)(idx % H);
+            const long row = idx / H;
+            const int b = (int)(row / N), q = (int)(row - (long)b * N);
+            delta[((size_t)b * H + h) * N + q] = s;
+        }
+        return;
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;  // over B * N * H, head fastest
     if (idx >= B * N * H) return;
     const int h = idx % H, row = idx / H;            // row = b * N + q
@@ -287,8 +310,9 @@ int launch_bwd_part(const void* qkv, const void* dO, const float* lse, const flo
 template <int DH>
 int launch_bwd(const void* qkv, const void* O, const void* dO, const float* lse, float* delta, void* dqkv, int batch,
                int N, int H, hipStream_t stream) {
-    const int total = batch * N * H;
-    hipLaunchKernelGGL(attn_delta_kernel<DH>, dim3(ceil_div(total, 256)), dim3(256), 0, stream, (const bf16_t*)O,
+    constexpr int CPH = DH / 8;
+    const long total = (long)batch * N * H * (((CPH & (CPH - 1)) == 0 && CPH <= 16) ? CPH : 1);
+    hipLaunchKernelGGL(attn_delta_kernel<DH>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)O,
                        (const bf16_t*)dO, delta, batch, N, H);
     VIT_CHECK_HIP(hipGetLastError());
     int rc = launch_bwd_part<DH, MODE_DQ>(qkv, dO, lse, delta, dqkv, batch, N, H, stream);
