@@ -397,16 +397,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                 const float4 b0 = *(const float4*)(P.bias + nb);
                 bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
             }
-            // LayerNorm folded in: the tile's (mean * rstd, rstd) are in LDS behind the ring (DMA of the last K-tile);
-            // a lane's rows come in runs of four (32 bytes), and the column sums of the folded weight
-            f32x4 lst[LNF ? 16 : 1];
+            // LayerNorm folded in: the tile's (mean * rstd, rstd) are in LDS behind the ring (DMA of the last K-tile),
+            // read two rows at a time right where they are used (fetching all 32 rows' pairs up front held 64 more
+            // VGPRs through the epilogue and cost 7-8 us per launch); and the column sums of the folded weight
             float lnc[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (LNF) {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int lr = (s >> 3) * 128 + wr * 64 + ((s >> 1) & 3) * 16 + 4 * q + (s & 1) * 2;
-                    lst[s] = *(const f32x4*)(smem + LDS_BYTES + lr * 8);
-                }
                 if (col_ok) {
                     const float4 c4 = *(const float4*)(P.ln_c + nb);
                     lnc[0] = c4.x; lnc[1] = c4.y; lnc[2] = c4.z; lnc[3] = c4.w;
@@ -430,7 +425,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                         const unsigned voff = voff0 + (unsigned)((ha * 128 + mi * 16 + j) * P.N) * 2u;
                         float v[4];
                         if constexpr (LNF) {
-                            const f32x4 sp = lst[ha * 8 + mi * 2 + (j >> 1)];  // two rows' (mean * rstd, rstd)
+                            // two rows' (mean * rstd, rstd)
+                            const f32x4 sp = *(const f32x4*)(smem + LDS_BYTES + (ha * 128 + wr * 64 + mi * 16 + 4 * q + (j >> 1) * 2) * 8);
                             const float mr = (j & 1) ? sp[2] : sp[0], rs = (j & 1) ? sp[3] : sp[1];
                             // two packed fmas per column pair (same bits as the fmaf chain of the generic kernel)
 #pragma unroll
