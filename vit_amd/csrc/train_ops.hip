@@ -10,6 +10,8 @@
 
 namespace {
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------ transpose (+ column sums)
 // src: [R, C] bf16 (row r lives at memory row r, or r + r/group + 1 when group > 0: the token
 // rows of [B, N, D] without the CLS rows). dst: [C, Rpad] bf16, columns R..Rpad zero.
@@ -104,22 +106,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         ag[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         ab[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int row = wave_in_grid; row < rows; row += nwaves) {
-        f32x4 xv[NIT], gv[NIT];
-        float s = 0.f;
+    // the next row's x / dy / residual gradient are loaded (raw) before this row's four wave reductions run
+    u32x2 nx[NIT], nd[NIT], nr[NIT];
+    auto fetch = [&](int row) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = (it * 64 + lane) * 4;
-            xv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < dim) {
-                const bf16x4 a = *(const bf16x4*)(x + (size_t)row * xs + c);
-                const bf16x4 b = *(const bf16x4*)(dy + (size_t)row * dys + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { xv[it][e] = (float)a[e]; gv[it][e] = (float)b[e]; }
-                s += (xv[it][0] + xv[it][1]) + (xv[it][2] + xv[it][3]);
+            nx[it] = nd[it] = nr[it] = u32x2{0u, 0u};
+            if (c < dim && row < rows) {
+                nx[it] = *(const u32x2*)(x + (size_t)row * xs + c);
+                nd[it] = *(const u32x2*)(dy + (size_t)row * dys + c);
+                if (dres != nullptr) nr[it] = *(const u32x2*)(dres + (size_t)row * dxs + c);
             }
         }
+    };
+    fetch(wave_in_grid);
+    for (int row = wave_in_grid; row < rows; row += nwaves) {
+        f32x4 xv[NIT], gv[NIT];
+        u32x2 rv[NIT];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const bf16x4 a = __builtin_bit_cast(bf16x4, nx[it]), b = __builtin_bit_cast(bf16x4, nd[it]);
+            rv[it] = nr[it];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[it][e] = (float)a[e]; gv[it][e] = (float)b[e]; }
+            s += (xv[it][0] + xv[it][1]) + (xv[it][2] + xv[it][3]);
+        }
+        fetch(row + nwaves);
         const float mean = wave_sum(s) * inv_d;
         float ss = 0.f;
 #pragma unroll
@@ -160,7 +174,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[it][e] - s1 - xv[it][e] * s2);
                 if (dres != nullptr) {
-                    const bf16x4 r = *(const bf16x4*)(dres + (size_t)row * dxs + c);
+                    const bf16x4 r = __builtin_bit_cast(bf16x4, rv[it]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += (float)r[e];
                 }
