@@ -6,10 +6,10 @@
 // both operands K-contiguous, which cost two transposes per weight gradient (15 % of the training
 // step); this kernel reads the token-major tiles as they are and transposes inside the LDS read:
 //
-//  * tile 256 (m) x 256 (n) x 64 tokens, 8 waves (2 x 4), wave tile 128 x 64, one workgroup per CU,
-//    two LDS buffers of [64 tokens][256 features] per operand, fed by buffer-resource LDS-DMA
-//    (rows past T are outside the resource and read as zero: no padded copies), one barrier per
-//    K-tile, the next tile's DMA under the current tile's MFMAs.
+//  * tile 256 (m) x 256 (n), 8 waves (2 x 4), wave tile 128 x 64, one workgroup per CU, an LDS ring of
+//    four slots of [32 tokens][256 features] per operand, fed by buffer-resource LDS-DMA three slots
+//    ahead (rows past T are outside the resource and read as zero: no padded copies), one counted
+//    vmcnt wait and one barrier per slot.
 //  * MFMA fragments (16 features x 32 tokens, 8 consecutive tokens per lane) come out of the
 //    token-major tile through ds_read_b64_tr_b16: a 16-lane group loads 4 token rows x 16 features
 //    and each lane receives one feature's 4 tokens. 8 token rows x 32 bytes are read per LDS cycle,
@@ -24,9 +24,8 @@
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int TILE_BYTES = BK * BM * 2;      // 32 KB: one operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;    // A then B
-constexpr int LDS_BYTES = 2 * BUF_BYTES;     // two buffers
+constexpr int SLOT_BYTES = 32768;            // 32 tokens x 256 features of A (16 KB) then of B (16 KB)
+constexpr int LDS_BYTES = 4 * SLOT_BYTES;    // ring of four slots
 
 struct TnParams {
     const bf16_t* A;   // dY [T, Mo]
@@ -68,29 +67,31 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int t_begin = split * P.tok_per_split;
-    const int nk = P.tok_per_split / BK;
 
-    // ---- DMA staging: wave w, piece j covers token rows 2*(4w + j) + (lane >> 5), 16-byte chunk lane & 31
+    // ---- DMA staging (16-byte chunk lane & 31 of a token row)
     const __amdgpu_buffer_rsrc_t Ar =
         __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (unsigned)P.T * (unsigned)P.Mo * 2u, 0x00020000);
     const __amdgpu_buffer_rsrc_t Br =
         __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (unsigned)P.T * (unsigned)P.No * 2u, 0x00020000);
-    unsigned a_src[4], b_src[4];
+    // four slots of 32 tokens ([A 16 KB][B 16 KB]); wave w, piece j covers token rows 2*(2w + j) + (lane >> 5)
+    unsigned ra_src[2], rb_src[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = 2 * (4 * wave + j) + (lane >> 5);
+    for (int j = 0; j < 2; ++j) {
+        const int r = 2 * (2 * wave + j) + (lane >> 5);
         const int p = lane & 31;
-        const int c = ((((p >> 1) ^ swz(r)) << 1) | (p & 1)) * 8;  // first feature of the chunk this lane fetches
-        a_src[j] = (m0 + c < P.Mo) ? (unsigned)(r * P.Mo + m0 + c) * 2u : 0x80000000u;
-        b_src[j] = (n0 + c < P.No) ? (unsigned)(r * P.No + n0 + c) * 2u : 0x80000000u;
+        const int c = ((((p >> 1) ^ swz(r)) << 1) | (p & 1)) * 8;
+        ra_src[j] = (m0 + c < P.Mo) ? (unsigned)(r * P.Mo + m0 + c) * 2u : 0x80000000u;
+        rb_src[j] = (n0 + c < P.No) ? (unsigned)(r * P.No + n0 + c) * 2u : 0x80000000u;
     }
-    auto stage = [&](int buf, int kt) {
-        unsigned char* d = smem + buf * BUF_BYTES + wave * 4096;
-        const int tok = t_begin + kt * BK;
+    const int ns = P.tok_per_split / 32;
+    auto stage_slot = [&](int s) {  // slots past the split's end are fetched out of range (zeros, no traffic): vmcnt stays uniform
+        unsigned char* d = smem + (s & 3) * SLOT_BYTES + wave * 2048;
+        const int tok = t_begin + s * 32;
+        const unsigned kill = s < ns ? 0u : 0x80000000u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, LDS_PTR(d + j * 1024), 16, (int)a_src[j], tok * P.Mo * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, LDS_PTR(d + TILE_BYTES + j * 1024), 16, (int)b_src[j],
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, LDS_PTR(d + j * 1024), 16, (int)(ra_src[j] | kill), tok * P.Mo * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(Br, LDS_PTR(d + SLOT_BYTES / 2 + j * 1024), 16, (int)(rb_src[j] | kill),
                                                      tok * P.No * 2, 0, 0);
         }
     };
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) a_off[mi] = smem_lds + rowpart + (unsigned)(((wm * 8 + mi) ^ f) * 32);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) b_off[ni] = smem_lds + TILE_BYTES + rowpart + (unsigned)(((wn * 4 + ni) ^ f) * 32);
+    for (int ni = 0; ni < 4; ++ni)
+        b_off[ni] = smem_lds + SLOT_BYTES / 2 + rowpart + (unsigned)(((wn * 4 + ni) ^ f) * 32);
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -117,23 +119,17 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // tile kt landed; buffer buf^1 is free again
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        const unsigned bo = (unsigned)(buf * BUF_BYTES);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+    // one k-step: the 32 tokens of the slot at LDS byte offset bo
+    auto kstep = [&](const unsigned bo) {
             short4v bl[4], bh[4], al[8], ah[8];
             // B fragments and the first four A fragments, then the other four A under the first MFMAs
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                if (ks == 0) TR2(bl[ni], bh[ni], b_off[ni] + bo, 0); else TR2(bl[ni], bh[ni], b_off[ni] + bo, 16384);
+                TR2(bl[ni], bh[ni], b_off[ni] + bo, 0);
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                if (ks == 0) TR2(al[mi], ah[mi], a_off[mi] + bo, 0); else TR2(al[mi], ah[mi], a_off[mi] + bo, 16384);
+                TR2(al[mi], ah[mi], a_off[mi] + bo, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]),
@@ -141,7 +137,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
                            "+v"(al[3]), "+v"(ah[3])::"memory");
 #pragma unroll
             for (int mi = 4; mi < 8; ++mi) {
-                if (ks == 0) TR2(al[mi], ah[mi], a_off[mi] + bo, 0); else TR2(al[mi], ah[mi], a_off[mi] + bo, 16384);
+                TR2(al[mi], ah[mi], a_off[mi] + bo, 0);
             }
             bf16x8 bfr[4];
 #pragma unroll
@@ -166,8 +162,19 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
                 if (do_bias) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
             }
-        }
+    };
+    // Prefetch distance of three slots: before slot s is read, this wave's DMAs of slots s+1 and s+2 (8 instructions)
+    // may still be in flight (two 64-token buffers with vmcnt(0) per tile were 2.7 % slower; reading slot s+1's first
+    // fragments under slot s's last MFMAs, which shortens the DMA distance to two slots, was 0.7 % slower again).
+    stage_slot(0);
+    stage_slot(1);
+    stage_slot(2);
+    for (int s = 0; s < ns; ++s) {
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // slot s landed everywhere; slot s-1 is free
+        stage_slot(s + 3);
+        kstep((unsigned)((s & 3) * SLOT_BYTES));
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the out-of-range tail DMAs still target this LDS
 
     // ---- epilogue: D = (X^T-fragment rows n) x (dY^T-fragment cols m): lane holds m = lane & 15 and the
     // four consecutive n = 4 * (lane >> 4) + e  ->  one 16-byte store per fragment
