@@ -203,27 +203,34 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
         }
     }
 
-    // ---- store: lane = outer row, registers = d (4 consecutive per group)
-    if (o0 + r < N) {
-        bf16_t* op = dqkv + ((size_t)b * N + o0 + r) * rs + (size_t)h * DH + (MODE == MODE_DKV ? D : 0);
+    // ---- store: the accumulators hold lane = outer row, registers = d (4 consecutive per group). Written from there,
+    // one head's 128-byte row segment went out as 16 separate 8-byte pieces; the tile is turned through a wave-private
+    // LDS block instead (the operand images are dead after the barrier) and leaves as 16-byte chunks, 8 lanes per row.
+    __syncthreads();
+    unsigned char* ob = smem + (size_t)wave * 32 * G::RS;
+#pragma unroll
+    for (int which = 0; which < (MODE == MODE_DKV ? 2 : 1); ++which) {
 #pragma unroll
         for (int d = 0; d < G::DB; ++d)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d0 = d * 32 + 8 * g4 + 4 * hi;
                 if (d0 < DH) {
-                    bf16x4 v1;
+                    bf16x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v1[e] = (bf16_t)(acc1[d][g4 * 4 + e] * scale);
-                    *(bf16x4*)(op + d0) = v1;  // dQ (DQ) or dK (DKV)
-                    if constexpr (MODE == MODE_DKV) {
-                        bf16x4 v2;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v2[e] = (bf16_t)acc2[d][g4 * 4 + e];
-                        *(bf16x4*)(op + D + d0) = v2;  // dV
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = which == 0 ? (bf16_t)(acc1[d][g4 * 4 + e] * scale) : (bf16_t)acc2[d][g4 * 4 + e];
+                    *(bf16x4*)(ob + (size_t)r * G::RS + d0 * 2) = v;
                 }
             }
+        __syncthreads();  // (the block is wave-private; the barriers only pin the order of its writes and reads)
+        bf16_t* obase = dqkv + (size_t)b * N * rs + (size_t)h * DH + (MODE == MODE_DKV ? D : 0) + (which ? D : 0);
+        for (int idx = lane; idx < 32 * G::CHUNKS; idx += 64) {
+            const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+            const bf16x8 v = *(const bf16x8*)(ob + (size_t)row * G::RS + c * 16);
+            if (o0 + row < N) *(bf16x8*)(obase + (size_t)(o0 + row) * rs + c * 8) = v;  // dQ / dK (which 0), dV (which 1)
+        }
+        if (MODE == MODE_DKV && which == 0) __syncthreads();
     }
 }
 
@@ -293,11 +300,12 @@ int launch_bwd_part(const void* qkv, const void* dO, const float* lse, const flo
     int icmax = (LDS_MAX / per_row) / 32 * 32;
     int IC = ((N + 31) / 32) * 32;
     if (IC > icmax) IC = icmax;
-    const size_t lds = (size_t)IC * per_row;
+    size_t lds = (size_t)IC * per_row;
+    if (lds < (size_t)waves * 32 * G::RS) lds = (size_t)waves * 32 * G::RS;  // the store epilogue's per-wave blocks
     auto kern = attn_bwd_kernel<DH, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
-        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX + 8 * 1024));
         attr_set = true;
     }
     const float scale = 1.0f / sqrtf((float)DH);
