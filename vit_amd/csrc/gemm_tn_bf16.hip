@@ -17,8 +17,8 @@
 //    applied on the DMA's SOURCE address -- which makes those 8 segments cover all 64 banks.
 //  * split-K over tokens (few output tiles: 9 .. 144), one fp32 slab per split, summed in a fixed
 //    order by reduce_slabs (reproducible); the bias gradient (column sums of dY) rides along as one
-//    extra MFMA against a fragment of ones in the waves that own the first n-tile, and is added to
-//    db with one fp32 atomic per feature and workgroup (as the transpose kernel did before).
+//    extra MFMA against a fragment of ones, dealt out over n-tiles and wave columns, and is added to
+//    db with one fp32 atomic per feature and split (as the transpose kernel did before).
 #include "vit_common.h"
 
 namespace {
@@ -111,7 +111,16 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = (P.dbias != nullptr) && tn == 0 && wn == 0;  // wave-uniform
+    // Bias gradient: fragment row mi of this wave row belongs to ONE (n-tile, wave column) pair -- every n-tile sees the
+    // same dY rows, so the eight extra MFMAs per k-step are dealt out over n-tiles and wave columns (all eight in the
+    // wn = 0 waves of the first n-tile made those waves, and with them the whole launch, 25 % longer).
+    const int tn_mod = P.tiles_n < 8 ? P.tiles_n : 8;
+    unsigned bmask = 0;  // wave-uniform
+    if (P.dbias != nullptr) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+            if (tn == mi % tn_mod && wn == ((mi / tn_mod) & 3)) bmask |= 1u << mi;
+    }
     f32x4 bacc[8];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) bacc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
-                if (do_bias) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
+                if (bmask & (1u << mi)) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(al[4]), "+v"(ah[4]), "+v"(al[5]), "+v"(ah[5]), "+v"(al[6]), "+v"(ah[6]), "+v"(al[7]),
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
-                if (do_bias) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
+                if (bmask & (1u << mi)) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
             }
     };
     // Prefetch distance of three slots: before slot s is read, this wave's DMAs of slots s+1 and s+2 (8 instructions)
@@ -190,11 +199,11 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
             }
         }
     }
-    if (do_bias && q == 0) {
+    if (bmask != 0 && q == 0) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + wm * 128 + mi * 16 + i16;
-            if (m < P.Mo) atomicAdd(P.dbias + m, bacc[mi][0]);
+            if ((bmask & (1u << mi)) && m < P.Mo) atomicAdd(P.dbias + m, bacc[mi][0]);
         }
     }
 }
