@@ -262,10 +262,11 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
     if (ctx->nstreams > vit_ctx::kMaxStreams) ctx->nstreams = vit_ctx::kMaxStreams;
     if (ctx->nstreams > 1) {
         e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-        for (int i = 0; i < ctx->nstreams - 1 && e == hipSuccess; ++i) {
+        for (int i = 0; i < ctx->nstreams - 1 && e == hipSuccess; ++i)
             e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
-        }
+        // all join events exist whenever there is a side stream (the backward uses two of them on aux_stream[0])
+        for (int i = 0; i < vit_ctx::kMaxStreams - 1 && e == hipSuccess; ++i)
+            e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
         if (e != hipSuccess) {
             vit_destroy(ctx);
             return vit_set_error(VIT_E_HIP, "vit_create: stream / event creation failed: %s", hipGetErrorString(e));

@@ -13,6 +13,7 @@
 // reduction dimension is the token count, split over K into fp32 slabs that are summed in a
 // fixed order (reproducible; no atomics on matrices).
 #include "vit_ctx.h"
+#include <stdlib.h>
 
 #include <stdio.h>
 #include <string.h>
@@ -440,24 +441,46 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
         const Stash::Lay& y = st.lay[l];
         void* du = ws + tw.du;
         void* dqkv = ws + tw.dqkv;
+        // Weight gradients run on a side stream: a data-gradient GEMM with N = 768 has 2.31 rounds of tiles on 256 CUs
+        // and leaves most of the chip idle for its last round; the weight gradient of the same dY (one round of ~250
+        // workgroups) starts on the CUs it frees. `to_side` hands a freshly written dY to the side stream.
+        static const bool side_on = !(getenv("VIT_AMD_BWD_SIDE_STREAM") && atoi(getenv("VIT_AMD_BWD_SIDE_STREAM")) == 0);
+        hipStream_t sb = (side_on && g.big && ctx->nstreams > 1 && ctx->aux_stream[0]) ? ctx->aux_stream[0] : stream;
+        const bool two = sb != stream;
+        auto to_side = [&]() -> int {
+            if (two) {
+                VIT_CHECK_HIP(hipEventRecord(ctx->ev_fork, stream));
+                VIT_CHECK_HIP(hipStreamWaitEvent(sb, ctx->ev_fork, 0));
+            }
+            return VIT_OK;
+        };
         // ---- MLP branch: x_out = x_mid + fc2(act(fc1(LN2(x_mid))))   (modeling_vit.py:280-284)
-        VIT_TRY(wgrad(ctx, g, ws, tw, dx, g.D, S + y.h, g.F, g.M, 0, G + lg.w2, G + lg.b2, stream));
+        VIT_TRY(to_side());
+        VIT_TRY(wgrad(ctx, g, ws, tw, dx, g.D, S + y.h, g.F, g.M, 0, G + lg.w2, G + lg.b2, sb));
+        if (two) VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[0], sb));  // dx has been read
         VIT_TRY(launch_gemm(dx, lt.w2T, nullptr, S + y.u, du, g.M, g.F, g.D, dact, T, nullptr, nullptr, stream));
-        VIT_TRY(wgrad(ctx, g, ws, tw, du, g.F, S + y.ln2, g.D, g.M, 0, G + lg.w1, G + lg.b1, stream));
+        VIT_TRY(to_side());
+        VIT_TRY(wgrad(ctx, g, ws, tw, du, g.F, S + y.ln2, g.D, g.M, 0, G + lg.w1, G + lg.b1, sb));
         VIT_TRY(launch_gemm(du, lt.w1T, nullptr, nullptr, dln, g.M, g.D, g.F, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
         VIT_TRY(launch_layernorm_bwd(S + y.xmid, dln, lw.ln2_g, dx, dx2, G + lg.ln2_g, G + lg.ln2_b, g.M, g.D, g.D, g.D, g.D,
                                      c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
         // ---- attention branch: x_mid = x + o_proj(attn(qkv(LN1(x))))   (modeling_vit.py:273-277)
-        VIT_TRY(wgrad(ctx, g, ws, tw, dx2, g.D, S + y.ctx, g.D, g.M, 0, G + lg.wo, G + lg.bo, stream));
+        VIT_TRY(to_side());
+        VIT_TRY(wgrad(ctx, g, ws, tw, dx2, g.D, S + y.ctx, g.D, g.M, 0, G + lg.wo, G + lg.bo, sb));
         VIT_TRY(launch_gemm(dx2, lt.woT, nullptr, nullptr, dln, g.M, g.D, g.D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
         VIT_TRY(launch_attention_bwd(S + y.qkv, S + y.ctx, dln, (const float*)(S + y.lse), (float*)(ws + tw.delta), dqkv,
                                      batch, g.N, g.H, ctx->dh, stream));
         const bool has_qkv_bias = clip || c.qkv_bias;
+        VIT_TRY(to_side());
         VIT_TRY(wgrad(ctx, g, ws, tw, dqkv, 3 * g.D, S + y.ln1, g.D, g.M, 0, G + lg.wqkv, has_qkv_bias ? G + lg.bqkv : nullptr,
-                      stream));
+                      sb));
+        if (two) VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[1], sb));  // the side stream's last kernel of this stage
         VIT_TRY(launch_gemm(dqkv, lt.wqkvT, nullptr, nullptr, dln, g.M, g.D, 3 * g.D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
+        if (two) VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[0], 0));  // dx is overwritten next
         VIT_TRY(launch_layernorm_bwd(S + st.x[l], dln, lw.ln1_g, dx2, dx, G + lg.ln1_g, G + lg.ln1_b, g.M, g.D, g.D, g.D, g.D,
                                      c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
+        // join: du, dx2, dqkv and the slabs are free again when the next stage (or the caller) goes on
+        if (two) VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[1], 0));
         return VIT_OK;
     }
 
