@@ -119,6 +119,18 @@ size_t vit_workspace_bytes(const vit_ctx* ctx, int batch);
 int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
                 void* pooled_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* vit_forward for callers that cannot allocate or hold a workspace (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc). It has NO counterpart in the reference (which has no
+ * encoder at all, see the boundary note above). The workspace is a file-scope device array inside the
+ * library, VIT_STATIC_SCRATCH_BYTES per GPU, held until the process ends; the call and everything under it
+ * allocates nothing. Same arguments, results (bit for bit) and errors as vit_forward, minus the workspace;
+ * batches whose vit_workspace_bytes(ctx, batch) exceeds VIT_STATIC_SCRATCH_BYTES are rejected with
+ * VIT_E_NOMEM (ViT-B/16 bf16: up to 10 images per call). All calls on one GPU share that GPU's array:
+ * calls that overlap in time on one GPU (other streams, threads or contexts) race -- serialise them. */
+#define VIT_STATIC_SCRATCH_BYTES (32u << 20)
+int vit_forward_static(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
+                       void* pooled_out, void* stream);
+
 /* ---- per-kernel entry points (each unit-testable against oracle/vit_oracle.py) ---- */
 
 /* nn.LayerNorm over the last dim, biased variance, fp32 statistics (MV:261-262,274,281).

@@ -53,6 +53,7 @@ SIGNATURES = {
     "vit_missing_weights": (c_int, [c_void_p, POINTER(c_char_p)]),
     "vit_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vit_forward_static": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vit_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_float,
                                   c_int, c_void_p]),
     "vit_gemm_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

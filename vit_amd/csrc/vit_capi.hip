@@ -67,6 +67,23 @@ struct ArenaBuilder {
 
 }  // namespace
 
+// ---------------------------------------------------------------- static scratch (vit_forward_static)
+// Workspace of the no-allocation entry point: one file-scope device array per GPU, held until the process ends.
+// In host code `scratch` is only a stand-in for the symbol: its device address is asked for once per device in
+// vit_create (hipGetSymbolAddress with that device current) and kept in g_scratch_ptr; every use goes through it.
+static __device__ __align__(256) unsigned char scratch[VIT_STATIC_SCRATCH_BYTES];
+static const int kMaxDevices = 64;
+static unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+static int resolve_static_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return VIT_OK;  // vit_forward_static reports it when asked for
+    if (g_scratch_ptr[device]) return VIT_OK;
+    void* p = nullptr;
+    VIT_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = (unsigned char*)p;
+    return VIT_OK;
+}
+
 extern "C" const char* vit_last_error(void) { return g_err; }
 extern "C" int vit_abi_version(void) { return 1; }
 
@@ -95,6 +112,10 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
     vit_ctx* ctx = new vit_ctx();
     ctx->cfg = c;
     VIT_CHECK_HIP(hipGetDevice(&ctx->device));
+    if (int rc = resolve_static_scratch(ctx->device); rc != VIT_OK) {
+        delete ctx;
+        return rc;
+    }
     const int D = c.hidden_size, F = c.intermediate_size, L = c.num_hidden_layers;
     const int g = c.image_size / c.patch_size;
     ctx->N = g * g + 1;
@@ -437,6 +458,24 @@ extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype
         }
     }
     return VIT_OK;
+}
+
+// vit_forward on the library's static scratch array instead of a caller workspace: no hipMalloc / hipFree or any
+// allocating routine on this path (vit_forward itself allocates nothing). Every call on a GPU shares that GPU's
+// array, so calls that overlap on one GPU (two streams, two threads, two contexts) race; nothing in the workspace
+// has to start at zero (every buffer is written before it is read), so the last call's contents are harmless.
+extern "C" int vit_forward_static(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
+                                  void* pooled_out, void* stream) {
+    VIT_REQUIRE(ctx != nullptr, "vit_forward_static: null context");
+    VIT_REQUIRE(batch > 0, "vit_forward_static: batch must be positive (got %d)", batch);
+    const size_t need = vit_workspace_bytes(ctx, batch);
+    if (need > (size_t)VIT_STATIC_SCRATCH_BYTES)
+        return vit_set_error(VIT_E_NOMEM, "vit_forward_static: batch %d needs %zu workspace bytes, the static scratch holds %zu "
+                                          "(use vit_forward with a caller workspace)", batch, need, (size_t)VIT_STATIC_SCRATCH_BYTES);
+    if (ctx->device < 0 || ctx->device >= kMaxDevices || g_scratch_ptr[ctx->device] == nullptr)
+        return vit_set_error(VIT_E_STATE, "vit_forward_static: no static scratch resolved for device %d", ctx->device);
+    return vit_forward(ctx, pixels_dev, pixel_dtype, batch, hidden_out, pooled_out, g_scratch_ptr[ctx->device],
+                       (size_t)VIT_STATIC_SCRATCH_BYTES, stream);
 }
 
 // the whole forward of `batch` images on one stream
