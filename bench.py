@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec, ViT-B/16 224^2 bf16 forward (BASELINE.json configs[1]).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W      (N > 1: this process starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  --config {b16,l14,h14} --scaling {weak,strong} --batch B select BASELINE.json configs[2] / [3]
+  (default: configs[1], ViT-B/16, weak scaling, 256 images per GPU).
 
 A step = one forward of the hot path (vit_forward through the C ABI) over one batch of 256
 synthetic images per GPU, already resident in HBM; for N > 1 the batch is sharded (weak
@@ -198,6 +200,31 @@ def train_main(args, cfg, enc, px, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+CONFIGS = {
+    # key: (ViTConfig factory, short name, BASELINE.json config, default scaling, default batch
+    #       [weak: images per GPU; strong: global images])
+    "b16": (ViTConfig.vit_b16_224, "ViT-B/16 224^2", "configs[1]", "weak", 256),
+    "l14": (ViTConfig.clip_l14_336, "ViT-L/14 336^2 (CLIP vision tower)", "configs[2]", "strong", 128),
+    "h14": (ViTConfig.vit_h14_448, "ViT-H/14 448^2", "configs[3]", "weak", 32),
+}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` as typed: this parent has touched no GPU (nothing above initialises HIP) and starts
+    N fresh rank processes through torch.distributed.run as a CHILD process (never an exec), then exits with its
+    code. The ranks re-enter this file with RANK / LOCAL_RANK / WORLD_SIZE set."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,13 +235,22 @@ def main():
     ap.add_argument("--workload", choices=("forward", "train"), default="forward",
                     help="forward = the headline metric (BASELINE.json configs[1]); train = fwd+bwd+SGD step with the "
                          "gradient all-reduce (configs[4]), reported as images/sec of the training step")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="b16",
+                    help="b16 = ViT-B/16 224 (configs[1], the headline), l14 = CLIP ViT-L/14 336 (configs[2]), "
+                         "h14 = ViT-H/14 448 (configs[3])")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak: --batch images per GPU; strong: --batch images in all, sharded over the GPUs "
+                         "(default: weak for b16 / h14, strong for l14 as configs[2] asks)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak) or global images (strong)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -222,18 +258,33 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
-    cfg = ViTConfig.vit_b16_224()
+    factory, cname, cref, dscaling, dbatch = CONFIGS[args.config]
+    scaling = args.scaling or dscaling
+    batch = args.batch or dbatch
+    cfg = factory()
+    if scaling == "weak":
+        local_batch, global_batch = batch, batch * world
+        lo = rank * batch
+    else:
+        from vit_amd.dist import shard_bounds
+        global_batch = batch
+        lo, hi = shard_bounds(global_batch, rank, world)
+        local_batch = hi - lo
+        if local_batch == 0:
+            raise SystemExit(f"strong scaling: global batch {global_batch} leaves rank {rank} of {world} empty")
     enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=dev)
     enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0, device=dev))
-    px = synth.synthetic_images(cfg, LOCAL_BATCH, seed=1 + rank, device=dev).to(torch.bfloat16)
+    px = synth.synthetic_images(cfg, local_batch, seed=1 + rank, device=dev).to(torch.bfloat16)
     if args.workload == "train":
+        if args.config != "b16" or scaling != "weak" or batch != LOCAL_BATCH:
+            raise SystemExit("--workload train is BASELINE.json configs[4]: ViT-B/16, weak scaling, 256 images per GPU")
         return train_main(args, cfg, enc, px, rank, world, dev, dist)
-    gathered = torch.empty(world * LOCAL_BATCH, cfg.hidden_size, dtype=torch.bfloat16, device=dev) if world > 1 else None
+    from vit_amd.dist import all_gather_rows
 
     def step():
         out = enc(px)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out.pooler_output)
+        if world > 1:  # the path's one exchange step: all-gather of the CLS embeddings (RCCL)
+            all_gather_rows(out.pooler_output, global_batch)
         return out
 
     def fence():
@@ -256,30 +307,33 @@ def main():
     assert torch.isfinite(out.pooler_output).all(), "non-finite embeddings"
 
     if rank == 0:
-        images = world * LOCAL_BATCH * args.steps
+        images = global_batch * args.steps
         value = images / elapsed
         flops = value * cfg.flops_per_image()
+        per = f"batch {batch} per MI355X" if scaling == "weak" else f"global batch {batch} sharded over {world} MI355X"
         line = {
-            "metric": "images/sec ViT-B/16 224^2 bf16 forward", "value": value, "unit": "images/sec",
+            "metric": f"images/sec {cname} bf16 forward" if args.config != "b16" else "images/sec ViT-B/16 224^2 bf16 forward",
+            "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ViT-B/16 224^2 bf16 forward, batch 256 per MI355X (BASELINE.json configs[1])",
-                       "global_batch": world * LOCAL_BATCH, "seq_len": cfg.seq_len,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{cname} bf16 forward, {per} (BASELINE.json {cref})",
+                       "global_batch": global_batch, "seq_len": cfg.seq_len,
                        "parallelism": f"dp{world}" + (" + RCCL all-gather of CLS embeddings" if world > 1 else "")},
             "end_to_end": {"achieved": flops / 1e12, "peak": world * MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                            "frac": flops / (world * MFMA_BF16_PEAK)},
         }
         if not args.no_kernels:
-            ks = kernel_rooflines(cfg, LOCAL_BATCH, dev)
+            ks = kernel_rooflines(cfg, local_batch, dev)
             dom = max((k for k in ks if k.startswith("gemm")),
                       key=lambda k: ks[k]["us_per_launch"] * ks[k]["launches_per_forward"])
             r = ks[dom]
             line["roofline"] = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
-                                "frac": r["frac"], "traffic": pmc_traffic_bytes(dom),
-                                "kernel": "g8::gemm8p_persist_kernel (" + dom + ")", "us_per_launch": r["us_per_launch"]}
+                                "frac": r["frac"],
+                                "traffic": pmc_traffic_bytes(dom) if (args.config == "b16" and local_batch == LOCAL_BATCH) else None,
+                                "kernel": "bf16 MFMA GEMM (" + dom + ")", "us_per_launch": r["us_per_launch"]}
             line["kernels"] = ks
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(ViTConfig.vit_b16_224())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

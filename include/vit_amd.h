@@ -107,7 +107,7 @@ size_t vit_workspace_bytes(const vit_ctx* ctx, int batch);
  *   pooled_out   [batch, D]    in the context dtype  (ViT: CLS row of hidden_out;
  *                CLIP: post_layernorm of the CLS row). May be NULL.
  *   workspace    >= vit_workspace_bytes(ctx, batch) bytes, 256-byte aligned.
- * VIT_BF16 contexts run batches of >= 2 x 6304 token rows (64 images at 197 tokens) as two contiguous halves, one on `stream` and one on
+ * VIT_BF16 contexts run batches of >= 2 x 6304 token rows (2 x 32 images at 197 tokens) as two contiguous halves, one on `stream` and one on
  * a stream the context owns (forked from and joined back into `stream` with events, so the call
  * keeps its stream semantics and stays graph-capturable): one half's kernels occupy the CUs the
  * other half's last round of GEMM tiles leaves idle (+5 % images/s at ViT-B/16 batch 256).

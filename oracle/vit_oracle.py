@@ -62,6 +62,13 @@ def layer_norm(x, weight, bias, eps):
     return (x - mu) / torch.sqrt(var + eps) * weight + bias
 
 
+def linear(x, weight, bias=None):
+    """nn.Linear, weight [out, in]: the q/k/v, o_proj, fc1 and fc2 projections (modeling_vit.py:216-218, :236,
+    :250-252; CLIP modeling_clip.py:296-333, :349-353)."""
+    y = x @ weight.t()
+    return y if bias is None else y + bias
+
+
 def activation(x, name):
     if name == "gelu":  # exact erf GELU, configuration_vit.py:54
         return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))

@@ -64,7 +64,7 @@ def test_bf16_matches_golden_vit_b16():
 
 
 @pytest.mark.parametrize("name,dtype", [("clip_l14_336", torch.bfloat16), ("clip_l14_336", torch.float32),
-                                        ("vit_h14_448", torch.bfloat16)])
+                                        ("vit_h14_448", torch.bfloat16), ("vit_h14_448", torch.float32)])
 def test_large_configs_match_golden(name, dtype):
     cfg, batch, fx = load_golden(name)
     out = build(cfg, dtype)(synth.synthetic_images(cfg, batch, seed=1))

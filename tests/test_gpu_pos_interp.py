@@ -1,6 +1,7 @@
 """Position-embedding interpolation through the C ABI: the kernel against the golden
 vectors from transformers, and a resized context against the oracle run at the new resolution."""
 import ctypes
+import dataclasses
 import os
 
 import numpy as np
@@ -14,6 +15,7 @@ from vit_amd.config import ViTConfig
 from vit_amd.encoder import ViTEncoder
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 
 def _interp(pos, d, gs, gh, gw):
@@ -93,3 +95,47 @@ def test_clone_requires_loaded_weights():
     enc = ViTEncoder(cfg, dtype=torch.float32, device="cuda:0")
     with pytest.raises(_lib.VitError, match="not loaded"):
         enc.with_image_size(48)
+
+
+def test_resized_clone_follows_weight_changes():
+    """A clone made by with_image_size() holds a copy of the weights: after load_state_dict() or an SGD step the
+    cached clone must not be served again."""
+    from vit_amd.trainer import ViTTrainer
+    cfg = ViTConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, image_size=32, patch_size=8)
+    enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
+    enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0))
+    px = synth.synthetic_images(dataclasses.replace(cfg, image_size=48), 3, seed=1, device=DEV).to(torch.bfloat16)
+    a = enc(px, interpolate_pos_encoding=True).pooler_output.clone()
+    # (1) new weights through load_state_dict
+    enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=5))
+    b = enc(px, interpolate_pos_encoding=True).pooler_output.clone()
+    fresh = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
+    fresh.load_state_dict(synth.synthetic_state_dict(cfg, seed=5))
+    assert torch.equal(b, fresh(px, interpolate_pos_encoding=True).pooler_output)
+    assert not torch.equal(a, b)
+    # (2) an SGD step
+    tr = ViTTrainer(enc)
+    p32 = synth.synthetic_images(cfg, 3, seed=2, device=DEV).to(torch.bfloat16)
+    out = tr.forward(p32)
+    tr.backward(None, torch.ones_like(out.pooler_output))
+    tr.sgd_step(0.5)
+    c = enc(px, interpolate_pos_encoding=True).pooler_output
+    assert not torch.equal(b, c)
+    # the clone of the updated encoder equals a clone made from scratch now
+    enc.weights_changed()
+    assert torch.equal(c, enc(px, interpolate_pos_encoding=True).pooler_output)
+
+
+def test_trainer_rejects_heads_and_pooler_keys_are_skipped():
+    from vit_amd.trainer import ViTTrainer
+    cfg = ViTConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=4, intermediate_size=128, image_size=32, patch_size=8)
+    sd = synth.synthetic_state_dict(cfg, seed=0)
+    sd_hf = dict(sd)  # a stock ViTModel checkpoint carries the pooler
+    sd_hf["pooler.dense.weight"] = torch.zeros(64, 64)
+    sd_hf["pooler.dense.bias"] = torch.zeros(64)
+    enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
+    enc.load_state_dict(sd_hf)  # strict, no 'unexpected key'
+    with_head = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV, add_pooling_layer=True)
+    with_head.load_state_dict(sd_hf)
+    with pytest.raises(ValueError, match="without a head"):
+        ViTTrainer(with_head)

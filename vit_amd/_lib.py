@@ -12,7 +12,8 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_
 VIT_F32, VIT_BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_DQUICK_GELU = 0, 1, 2, 3, 4, 5
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvit_amd.so")
+# VIT_AMD_LIB: another build of the same library (the host-sanitizer build of csrc/Makefile `asan`)
+LIB_PATH = os.environ.get("VIT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvit_amd.so")
 
 
 class VitLibraryError(RuntimeError):

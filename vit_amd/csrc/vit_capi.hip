@@ -443,21 +443,31 @@ extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype
     const size_t img = (size_t)c.num_channels * c.image_size * c.image_size;
     VIT_CHECK_HIP(hipEventRecord(ctx->ev_fork, stream));
     size_t ws_off = 0;
+    // After the fork every side stream is joined back into `stream` whatever happens in between: an error in
+    // one chunk must not leave a side stream running against the workspace when the call returns.
+    int rc = VIT_OK;
     for (int i = 0; i < k; ++i) {
         const int b0 = chunk_begin(batch, k, i), nb = chunk_begin(batch, k, i + 1) - b0;
         hipStream_t st = i == 0 ? stream : ctx->aux_stream[i - 1];
-        if (i > 0) VIT_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
-        VIT_TRY(forward_range(ctx, (const char*)pixels_dev + (size_t)b0 * img * pes, pixel_dtype, nb,
-                              (char*)hidden_out + (size_t)b0 * ctx->N * c.hidden_size * es,
-                              pooled_out ? (char*)pooled_out + (size_t)b0 * c.hidden_size * es : nullptr,
-                              (char*)workspace + ws_off, st));
+        bool forked = false;
+        if (i > 0 && rc == VIT_OK) {
+            const hipError_t e = hipStreamWaitEvent(st, ctx->ev_fork, 0);
+            if (e != hipSuccess) rc = vit_set_error(VIT_E_HIP, "vit_forward: hipStreamWaitEvent: %s", hipGetErrorString(e));
+            else forked = true;
+        }
+        if (rc == VIT_OK)
+            rc = forward_range(ctx, (const char*)pixels_dev + (size_t)b0 * img * pes, pixel_dtype, nb,
+                               (char*)hidden_out + (size_t)b0 * ctx->N * c.hidden_size * es,
+                               pooled_out ? (char*)pooled_out + (size_t)b0 * c.hidden_size * es : nullptr,
+                               (char*)workspace + ws_off, st);
         ws_off += plan_workspace(ctx, nb).total;
-        if (i > 0) {
-            VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[i - 1], st));
-            VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[i - 1], 0));
+        if (forked) {
+            hipError_t e = hipEventRecord(ctx->ev_join[i - 1], st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(stream, ctx->ev_join[i - 1], 0);
+            if (e != hipSuccess && rc == VIT_OK) rc = vit_set_error(VIT_E_HIP, "vit_forward: stream join: %s", hipGetErrorString(e));
         }
     }
-    return VIT_OK;
+    return rc;
 }
 
 // vit_forward on the library's static scratch array instead of a caller workspace: no hipMalloc / hipFree or any
@@ -552,15 +562,14 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
     if (!clip) {
         // final LayerNorm over all tokens; pooled = its CLS row (modeling_vit.py:385-388, no pooler)
         VIT_TRY(launch_layernorm(x, ctx->fin_g, ctx->fin_b, hidden_out, M, D, D, D, c.layer_norm_eps, T, stream));
-        if (pooled_out)
-            VIT_TRY(launch_layernorm(x, ctx->fin_g, ctx->fin_b, pooled_out, batch, D, (int64_t)N * D, D,
-                                     c.layer_norm_eps, T, stream));
+        if (pooled_out)  // the CLS rows of hidden_out, strided copy (same bits as a second LayerNorm launch on them)
+            VIT_CHECK_HIP(hipMemcpy2DAsync(pooled_out, (size_t)D * es, hidden_out, (size_t)N * D * es, (size_t)D * es, batch,
+                                           hipMemcpyDeviceToDevice, stream));
     } else if (pooled_out) {
         // post_layernorm on the CLS row only (modeling_clip.py:649-651)
         VIT_TRY(launch_layernorm(hidden_out, ctx->fin_g, ctx->fin_b, pooled_out, batch, D, (int64_t)N * D, D,
                                  c.layer_norm_eps, T, stream));
     }
-    (void)es;
     return VIT_OK;
 }
 

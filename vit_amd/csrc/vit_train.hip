@@ -34,6 +34,10 @@ struct TrainState {
     int nconv = 0;
     TransposeSlot* tr_table = nullptr;  // device: the 4 transposed weights of every layer (vit_train_refresh_transposes)
     int ntr = 0, tr_blocks = 0;
+    // what the last vit_forward_train wrote into the caller's stash: every backward stage must be called with the same
+    // batch (the stash layout is derived from it) and, for the embedding stage, the same pixel dtype
+    int fwd_batch = 0, fwd_pixel_dtype = -1;
+    const void* fwd_stash = nullptr;
 };
 
 int launch_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* db, float* slabs, int T, int Mo, int No,
@@ -372,6 +376,9 @@ extern "C" int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel
         return VIT_OK;
     };
 
+    ctx->train->fwd_batch = batch;
+    ctx->train->fwd_pixel_dtype = pixel_dtype;
+    ctx->train->fwd_stash = stash_;
     // as vit_forward: two halves on two streams, so one half's kernels fill the CUs the other half's last
     // round of GEMM tiles leaves idle (the stash keeps its single-batch layout)
     const int k = vit_num_chunks(ctx, batch) >= 2 ? 2 : 1;
@@ -379,11 +386,13 @@ extern "C" int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel
     const int h0 = (batch + 1) / 2;
     VIT_CHECK_HIP(hipEventRecord(ctx->ev_fork, stream));
     VIT_CHECK_HIP(hipStreamWaitEvent(ctx->aux_stream[0], ctx->ev_fork, 0));
-    VIT_TRY(run(0, h0, stream));
-    VIT_TRY(run(h0, batch - h0, ctx->aux_stream[0]));
-    VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[0], ctx->aux_stream[0]));
-    VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[0], 0));
-    return VIT_OK;
+    // from here on the side stream is joined back whatever happens (an error must not leave it running)
+    int rc = run(0, h0, stream);
+    if (rc == VIT_OK) rc = run(h0, batch - h0, ctx->aux_stream[0]);
+    hipError_t e = hipEventRecord(ctx->ev_join[0], ctx->aux_stream[0]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, ctx->ev_join[0], 0);
+    if (e != hipSuccess && rc == VIT_OK) rc = vit_set_error(VIT_E_HIP, "vit_forward_train: stream join: %s", hipGetErrorString(e));
+    return rc;
 }
 
 // ---------------------------------------------------------------- backward, in stages
@@ -395,6 +404,10 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
     VIT_TRY(check_train_ctx(ctx, "vit_backward_stage"));
     VIT_REQUIRE(ctx->train, "vit_backward_stage: call vit_train_init first");
     VIT_REQUIRE(stash_ && grads_ && workspace, "vit_backward_stage: null argument");
+    VIT_REQUIRE(batch > 0, "vit_backward_stage: batch must be positive (got %d)", batch);
+    VIT_REQUIRE(ctx->train->fwd_batch == batch && ctx->train->fwd_stash == stash_,
+                "vit_backward_stage: batch %d / stash %p do not match the last vit_forward_train (batch %d, stash %p)", batch,
+                stash_, ctx->train->fwd_batch, ctx->train->fwd_stash);
     const TGeo g = tgeo(ctx, batch);
     VIT_REQUIRE(stage >= 0 && stage <= g.L + 1, "vit_backward_stage: stage %d outside [0, %d]", stage, g.L + 1);
     const Stash st = plan_stash(ctx, batch);
@@ -454,39 +467,49 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
             }
             return VIT_OK;
         };
-        // ---- MLP branch: x_out = x_mid + fc2(act(fc1(LN2(x_mid))))   (modeling_vit.py:280-284)
-        VIT_TRY(to_side());
-        VIT_TRY(wgrad(ctx, g, ws, tw, dx, g.D, S + y.h, g.F, g.M, 0, G + lg.w2, G + lg.b2, sb));
-        if (two) VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[0], sb));  // dx has been read
-        VIT_TRY(launch_gemm(dx, lt.w2T, nullptr, S + y.u, du, g.M, g.F, g.D, dact, T, nullptr, nullptr, stream));
-        VIT_TRY(launch_gemm(du, lt.w1T, nullptr, nullptr, dln, g.M, g.D, g.F, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
-        VIT_TRY(launch_layernorm_bwd(S + y.xmid, dln, lw.ln2_g, dx, dx2, G + lg.ln2_g, G + lg.ln2_b, g.M, g.D, g.D, g.D, g.D,
-                                     c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
-        // ---- attention branch: x_mid = x + o_proj(attn(qkv(LN1(x))))   (modeling_vit.py:273-277)
-        // the fc1 weight gradient is handed over only here (du stays valid until the stage's join): beside the
-        // LayerNorm backward it only starved that kernel, beside the attention backward (byte-bound) it is free: -0.7 %
-        VIT_TRY(to_side());
-        VIT_TRY(wgrad(ctx, g, ws, tw, du, g.F, S + y.ln2, g.D, g.M, 0, G + lg.w1, G + lg.b1, sb));
-        VIT_TRY(wgrad(ctx, g, ws, tw, dx2, g.D, S + y.ctx, g.D, g.M, 0, G + lg.wo, G + lg.bo, sb));
-        VIT_TRY(launch_gemm(dx2, lt.woT, nullptr, nullptr, dln, g.M, g.D, g.D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
-        VIT_TRY(launch_attention_bwd(S + y.qkv, S + y.ctx, dln, (const float*)(S + y.lse), (float*)(ws + tw.delta), dqkv,
-                                     batch, g.N, g.H, ctx->dh, stream));
-        const bool has_qkv_bias = clip || c.qkv_bias;
-        VIT_TRY(to_side());
-        VIT_TRY(wgrad(ctx, g, ws, tw, dqkv, 3 * g.D, S + y.ln1, g.D, g.M, 0, G + lg.wqkv, has_qkv_bias ? G + lg.bqkv : nullptr,
-                      sb));
-        if (two) VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[1], sb));  // the side stream's last kernel of this stage
-        VIT_TRY(launch_gemm(dqkv, lt.wqkvT, nullptr, nullptr, dln, g.M, g.D, 3 * g.D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
-        if (two) VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[0], 0));  // dx is overwritten next
-        VIT_TRY(launch_layernorm_bwd(S + st.x[l], dln, lw.ln1_g, dx2, dx, G + lg.ln1_g, G + lg.ln1_b, g.M, g.D, g.D, g.D, g.D,
-                                     c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
-        // join: du, dx2, dqkv and the slabs are free again when the next stage (or the caller) goes on
-        if (two) VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[1], 0));
-        return VIT_OK;
+        auto layer_stage = [&]() -> int {
+            // ---- MLP branch: x_out = x_mid + fc2(act(fc1(LN2(x_mid))))   (modeling_vit.py:280-284)
+            VIT_TRY(to_side());
+            VIT_TRY(wgrad(ctx, g, ws, tw, dx, g.D, S + y.h, g.F, g.M, 0, G + lg.w2, G + lg.b2, sb));
+            if (two) VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[0], sb));  // dx has been read
+            VIT_TRY(launch_gemm(dx, lt.w2T, nullptr, S + y.u, du, g.M, g.F, g.D, dact, T, nullptr, nullptr, stream));
+            VIT_TRY(launch_gemm(du, lt.w1T, nullptr, nullptr, dln, g.M, g.D, g.F, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
+            VIT_TRY(launch_layernorm_bwd(S + y.xmid, dln, lw.ln2_g, dx, dx2, G + lg.ln2_g, G + lg.ln2_b, g.M, g.D, g.D, g.D, g.D,
+                                         c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
+            // ---- attention branch: x_mid = x + o_proj(attn(qkv(LN1(x))))   (modeling_vit.py:273-277)
+            // the fc1 weight gradient is handed over only here (du stays valid until the stage's join): beside the
+            // LayerNorm backward it only starved that kernel, beside the attention backward (byte-bound) it is free: -0.7 %
+            VIT_TRY(to_side());
+            VIT_TRY(wgrad(ctx, g, ws, tw, du, g.F, S + y.ln2, g.D, g.M, 0, G + lg.w1, G + lg.b1, sb));
+            VIT_TRY(wgrad(ctx, g, ws, tw, dx2, g.D, S + y.ctx, g.D, g.M, 0, G + lg.wo, G + lg.bo, sb));
+            VIT_TRY(launch_gemm(dx2, lt.woT, nullptr, nullptr, dln, g.M, g.D, g.D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
+            VIT_TRY(launch_attention_bwd(S + y.qkv, S + y.ctx, dln, (const float*)(S + y.lse), (float*)(ws + tw.delta), dqkv,
+                                         batch, g.N, g.H, ctx->dh, stream));
+            const bool has_qkv_bias = clip || c.qkv_bias;
+            VIT_TRY(to_side());
+            VIT_TRY(wgrad(ctx, g, ws, tw, dqkv, 3 * g.D, S + y.ln1, g.D, g.M, 0, G + lg.wqkv, has_qkv_bias ? G + lg.bqkv : nullptr,
+                          sb));
+            if (two) VIT_CHECK_HIP(hipEventRecord(ctx->ev_join[1], sb));  // the side stream's last kernel of this stage
+            VIT_TRY(launch_gemm(dqkv, lt.wqkvT, nullptr, nullptr, dln, g.M, g.D, 3 * g.D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
+            if (two) VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[0], 0));  // dx is overwritten next
+            VIT_TRY(launch_layernorm_bwd(S + st.x[l], dln, lw.ln1_g, dx2, dx, G + lg.ln1_g, G + lg.ln1_b, g.M, g.D, g.D, g.D, g.D,
+                                         c.layer_norm_eps, stream, (float*)(ws + tw.lnred)));
+            // join: du, dx2, dqkv and the slabs are free again when the next stage (or the caller) goes on
+            if (two) VIT_CHECK_HIP(hipStreamWaitEvent(stream, ctx->ev_join[1], 0));
+            return VIT_OK;
+        };
+        const int rc = layer_stage();
+        if (rc != VIT_OK && two) {
+            // error path: whatever the side stream was handed must still be joined before the caller reuses the buffers
+            if (hipEventRecord(ctx->ev_join[1], sb) == hipSuccess) (void)hipStreamWaitEvent(stream, ctx->ev_join[1], 0);
+        }
+        return rc;
     }
 
     // ---- embeddings (modeling_vit.py:129-161, 62-69; modeling_clip.py:202-218, 642)
     VIT_REQUIRE(pixels_dev != nullptr, "vit_backward_stage: the embedding stage needs the pixels");
+    VIT_REQUIRE(pixel_dtype == ctx->train->fwd_pixel_dtype, "vit_backward_stage: pixel dtype %d differs from vit_forward_train's %d",
+                pixel_dtype, ctx->train->fwd_pixel_dtype);
     const void* dxe = dx;
     if (clip) {
         VIT_TRY(launch_layernorm_bwd(S + st.xe, dx, ctx->pre_g, nullptr, dx2, G + ctx->g_pre_g, G + ctx->g_pre_b, g.M, g.D,

@@ -81,6 +81,7 @@ class ViTEncoder:
         optional ``vit.`` / ``vision_model.`` prefix is stripped). q/k/v are packed inside the
         library. With strict=True unknown keys and missing tensors raise."""
         lib = _lib.load()
+        self.weights_changed()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             for key, t in state_dict.items():
@@ -89,6 +90,10 @@ class ViTEncoder:
                     if name.startswith(prefix):
                         name = name[len(prefix):]
                 if not torch.is_tensor(t) or not t.is_floating_point():
+                    continue
+                if name.startswith("pooler.dense.") and self.config.variant == "vit" and not self.add_pooling_layer:
+                    # a stock ViTModel checkpoint (HF default add_pooling_layer=True) carries the pooler; this encoder
+                    # was built without it (our default), so the two tensors are not needed
                     continue
                 if name in self._head_keys():
                     want = self._head_keys()[name]
@@ -116,6 +121,12 @@ class ViTEncoder:
             for k in self._head_keys():
                 if k not in self._head:
                     raise KeyError(f"1 tensors missing from state_dict, e.g. {k!r}")
+
+    def weights_changed(self) -> None:
+        """Drop the per-resolution clones made by ``with_image_size`` (each holds a device copy of the weights as
+        they were when it was made). Called by ``load_state_dict`` and by ``ViTTrainer.sgd_step``."""
+        for e in self.__dict__.pop("_resized", {}).values():
+            e.close()
 
     def _head_keys(self) -> dict:
         d = self.config.hidden_size
@@ -147,7 +158,7 @@ class ViTEncoder:
     def with_image_size(self, image_size: int) -> "ViTEncoder":
         """A second encoder for ``image_size`` x ``image_size`` inputs: same weights, position table
         interpolated as ``interpolate_pos_encoding`` does (modeling_vit.py:89-127,
-        modeling_clip.py:161-200). Cached per size."""
+        modeling_clip.py:161-200). Cached per size until the weights change (``weights_changed``)."""
         if image_size == self.config.image_size:
             return self
         cache = self.__dict__.setdefault("_resized", {})

@@ -23,6 +23,11 @@ class ViTTrainer:
     def __init__(self, encoder: ViTEncoder):
         if encoder.dtype != torch.bfloat16:
             raise ValueError("the training step runs in bf16 (fp32 master weights and gradients)")
+        if encoder.add_pooling_layer or encoder.projection_dim is not None:
+            # the heads (vit_head_fwd) have no backward: training through them would silently leave the head weights
+            # without gradients and apply d_pooled to the wrong tensor
+            raise ValueError("ViTTrainer trains the encoder without a head: build the ViTEncoder with "
+                             "add_pooling_layer=False and projection_dim=None")
         self.enc = encoder
         self.cfg = encoder.config
         self.device = encoder.device
@@ -115,6 +120,7 @@ class ViTTrainer:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.vit_sgd_step(self.enc._ctx, self.grads.data_ptr(), float(lr),
                                               torch.cuda.current_stream().cuda_stream))
+        self.enc.weights_changed()  # resized clones (interpolate_pos_encoding) hold copies of the old weights
 
 
 class DataParallelTrainer:
