@@ -20,6 +20,7 @@
 //  * LDS rows are padded (K: dh*2+16 B, V: odd multiple of 64 B) -> conflict-free reads.
 #include "vit_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -372,6 +373,10 @@ int launch_attn_f32(const void* qkv, void* out, int batch, int N, int H, hipStre
 bool attention_dh64_eligible(int N);
 int launch_attention_dh64(const void* qkv, void* out, float* lse, int batch, int N, int H, hipStream_t stream);
 
+// persistent LDS-DMA ring for head dims whose rows are not 128 bytes (attention_ring.hip): head_dim 80 (ViT-H/14)
+bool attention_ring_eligible(int N, int head_dim);
+int launch_attention_ring(const void* qkv, void* out, float* lse, int batch, int N, int H, int head_dim, hipStream_t stream);
+
 int launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int head_dim, int dtype,
                      hipStream_t stream, float* lse) {
     VIT_REQUIRE(batch > 0 && seq > 0 && heads > 0, "attention: empty problem");
@@ -381,6 +386,9 @@ int launch_attention(const void* qkv, void* out, int batch, int seq, int heads, 
     VIT_REQUIRE(lse == nullptr || dtype == VIT_BF16, "attention: the log-sum-exp output is bf16-mode only");
     if (dtype == VIT_BF16 && head_dim == 64 && attention_dh64_eligible(seq))
         return launch_attention_dh64(qkv, out, lse, batch, seq, heads, stream);
+    static const bool ring_on = !(getenv("VIT_AMD_ATTN_RING") && atoi(getenv("VIT_AMD_ATTN_RING")) == 0);
+    if (dtype == VIT_BF16 && ring_on && attention_ring_eligible(seq, head_dim))
+        return launch_attention_ring(qkv, out, lse, batch, seq, heads, head_dim, stream);
 #define ATTN_CASE(DHV)                                                                          \
     case DHV:                                                                                   \
         return dtype == VIT_BF16 ? launch_attn_bf16<DHV>(qkv, out, lse, batch, seq, heads, stream) \

@@ -1,0 +1,359 @@
+// Fused multi-head self-attention forward for head dims that are not 64 (ViT-H/14: head_dim 80), bf16 -- the
+// persistent LDS-DMA ring of attention_dh64.hip carried over to rows that are not 128 bytes (same math:
+// eager_attention_forward, modeling_vit.py:164-189; fp32 online softmax, no mask, no score matrix; same MFMA dataflow
+// with the query on the lane as attention.hip / attention_dh64.hip).
+//
+// What changes with 160-byte rows:
+//  * LDS rows are PADDED (K and Q: 176 B = 11 chunks of 16 B, V: 192 B = 12 chunks) -- the strides attention.hip uses,
+//    conflict-free for ds_read_b128 (K, Q) and ds_read_b64_tr_b16 (V) without a swizzle. An LDS-DMA writes lane-linear,
+//    so a padded image needs the instruction's active lanes to cover whole padded rows: a wave's piece is FOUR rows,
+//    issued with 44 (K, Q) or 48 (V) lanes active; the lanes that land on pad chunks re-read the row's last chunk.
+//    Eight waves x 4 rows = one 32-key tile; every wave issues one K and one V instruction per tile.
+//  * Q K^T takes 5 k-steps, O^T = V^T P^T three 32-row blocks of head_dim (the third half empty), 11 MFMA per tile.
+//  * counted waits as in attention_dh64.hip with two DMA instructions per tile and eight Q pieces per item.
+#include "vit_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int NW = 8;  // waves per workgroup
+
+template <int DH>
+struct RingGeo {
+    static constexpr int CH = DH / 8;              // 16-byte chunks of a row
+    static constexpr int KCH = CH + 1;             // padded K / Q row, chunks (odd -> conflict-free ds_read_b128)
+    static constexpr int KROW = KCH * 16;
+    static constexpr int DB = (DH + 31) / 32;      // 32-row blocks of O^T
+    static constexpr int VCH = ((DB | 1) * 64) / 16;  // padded V row, chunks (odd multiple of 64 bytes)
+    static constexpr int VROW = VCH * 16;
+    static constexpr int KS = DH / 16;             // k-steps of Q K^T
+    static constexpr int KTILE = 32 * KROW, VTILE = 32 * VROW;
+    static constexpr int SLOT = KTILE + VTILE;     // one ring slot: K rows then V rows of 32 keys
+    static constexpr int QSLOT = 32 * KROW;        // one wave's 32 query rows
+    static constexpr int NQ = 8;                   // Q DMA pieces per wave and item (4 rows each)
+    static constexpr int ST = (DH + 7) / 8;        // output store instructions of an active wave per item (8 bytes per lane each)
+    static_assert(DH % 16 == 0 && 4 * KCH <= 64 && 4 * VCH <= 64, "a four-row piece must fit one wave instruction");
+};
+
+struct RingSrc {
+    const unsigned char* q;
+    const unsigned char* k;
+    const unsigned char* v;
+    long b_stride, h_stride;  // bytes
+    int rs2;                  // bytes between consecutive tokens of one head
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ bf16x8 pack8r(const f32x16& p, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)p[8 * s + e];
+    return o;
+}
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, unsigned lane_off, int uni_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, (int)lane_off, uni_off, 0, 0);
+}
+
+template <int DH, int R, bool LSE>
+__global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc src, bf16_t* __restrict__ out,
+                                                                  float* __restrict__ lse, int N, int H, int nitems,
+                                                                  int qblocks, float scale_log2e) {
+    using G = RingGeo<DH>;
+    constexpr int ST = G::ST + (LSE ? 1 : 0);
+    constexpr int NQ = G::NQ;
+    constexpr int C = 2;  // DMA instructions per wave and tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // R slots, then NW Q slots
+
+    const unsigned smem_lds = (unsigned)(uintptr_t)LDS_PTR(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const int D = H * DH;
+    const int rs2 = src.rs2;
+    const int nt = (N + 31) >> 5;
+
+    const int nmy = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (nmy <= 0) return;  // uniform
+
+    auto item_bh = [&](int j, int* qb) {
+        const int item = blockIdx.x + j * gridDim.x;
+        const int bh = item / qblocks;
+        *qb = item - bh * qblocks;
+        return bh;
+    };
+    auto item_rsrc = [&](const unsigned char* opbase, int bh) {
+        const int b = bh / H, h = bh - b * H;
+        const unsigned char* base = opbase + (size_t)b * src.b_stride + (size_t)h * src.h_stride;
+        const unsigned span = (unsigned)(N - 1) * (unsigned)rs2 + (unsigned)(DH * 2);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, span, 0x00020000);
+    };
+
+    // ---- this wave's pieces of a tile: K rows 4w..4w+3 (lanes 0..4*KCH-1) and V rows 4w..4w+3 (lanes 0..4*VCH-1)
+    const int k_prow = 4 * wave + lane / G::KCH, k_pc = lane % G::KCH;
+    const int v_prow = 4 * wave + lane / G::VCH, v_pc = lane % G::VCH;
+    const unsigned k_pconst = (unsigned)((k_pc < G::CH ? k_pc : G::CH - 1) * 16);
+    const unsigned v_pconst = (unsigned)((v_pc < G::CH ? v_pc : G::CH - 1) * 16);
+    const bool k_lane = lane < 4 * G::KCH, v_lane = lane < 4 * G::VCH;
+    unsigned char* const k_pdst = smem + 4 * wave * G::KROW;
+    unsigned char* const v_pdst = smem + G::KTILE + 4 * wave * G::VROW;
+    auto dma_tile = [&](__amdgpu_buffer_rsrc_t krs, __amdgpu_buffer_rsrc_t vrs, int t, int slot) {
+        const int lim = N - 1 - t * 32;  // rows past the sequence re-read its last row (their scores are masked)
+        const int kr = k_prow < lim ? k_prow : lim, vr = v_prow < lim ? v_prow : lim;
+        if (k_lane) dma16(krs, k_pdst + slot * G::SLOT, (unsigned)kr * (unsigned)rs2 + k_pconst, t * 32 * rs2);
+        if (v_lane) dma16(vrs, v_pdst + slot * G::SLOT, (unsigned)vr * (unsigned)rs2 + v_pconst, t * 32 * rs2);
+    };
+
+    // ---- read-side lane geometry
+    unsigned kro[G::KS];
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) kro[ks] = (unsigned)(r * G::KROW + (ks * 2 + hi) * 16);
+    const int g = lane >> 4, i16 = lane & 15;
+    const int tr_key = 4 * (g >> 1) + (i16 >> 2);
+    const int tr_col = ((g & 1) * 16 + 4 * (i16 & 3)) * 2;
+    const unsigned vro = (unsigned)(G::KTILE + tr_key * G::VROW + tr_col);  // + 16*sk*VROW (+ 8*VROW) + d*64
+
+    // ---- Q: the wave's 32 query rows go to its own LDS slot by DMA (8 pieces of 4 rows), one item ahead
+    unsigned char* const qslot = smem + R * G::SLOT + wave * G::QSLOT;
+    auto dma_q = [&](__amdgpu_buffer_rsrc_t rsrc, int q0) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            int qr = q0 + 4 * i + lane / G::KCH;
+            if (qr > N - 1) qr = N - 1;
+            if (k_lane) dma16(rsrc, qslot + i * 4 * G::KROW, (unsigned)qr * (unsigned)rs2 + k_pconst, 0);
+        }
+    };
+    bf16x8 qf[G::KS];
+
+    // ---- prologue
+    int qb;
+    int bh = item_bh(0, &qb);
+    int q0 = (qb * NW + wave) * 32;
+    __amdgpu_buffer_rsrc_t pkr = item_rsrc(src.k, bh), pvr = item_rsrc(src.v, bh);  // item the DMA cursor is in
+    dma_q(item_rsrc(src.q, bh), q0);
+    int pj = 0, pt = 0;
+    auto dma_next = [&](int slot) {
+        dma_tile(pkr, pvr, pt, slot);
+        if (pt + 1 < nt) {
+            ++pt;
+        } else if (pj + 1 < nmy) {
+            ++pj;
+            pt = 0;
+            int dummy;
+            const int nb = item_bh(pj, &dummy);
+            pkr = item_rsrc(src.k, nb);
+            pvr = item_rsrc(src.v, nb);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) dma_next(s);
+
+    f32x16 o[G::DB];
+#pragma unroll
+    for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int slot = 0, pslot = R - 1;
+    bool prev_active = false;
+    for (int j = 0; j < nmy; ++j) {
+        const bool active = q0 < N;  // wave-uniform
+        for (int p = 0; p < nt; ++p) {
+            // counted wait: this wave's pieces of the current tile have landed. Younger operations that may stay in
+            // flight: (R-2)*C tile DMAs; while p <= R-2 also the previous item's ST stores (if the wave had queries in
+            // it) and, from p = 1, the NQ loads of the Q prefetch.
+            {
+                const bool inwin = p <= R - 2;
+                const bool stin = inwin && prev_active;
+                const bool qin = inwin && p >= 1;
+                if (stin) {
+                    if (qin) wait_vm<(R - 2) * C + NQ + ST>(); else wait_vm<(R - 2) * C + ST>();
+                } else {
+                    if (qin) wait_vm<(R - 2) * C + NQ>(); else wait_vm<(R - 2) * C>();
+                }
+            }
+            asm volatile("s_barrier" ::: "memory");
+            if (p == 0) {
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) qf[ks] = *(const bf16x8*)(qslot + kro[ks]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+                const int jn = j + 1 < nmy ? j + 1 : j;
+                int nqb;
+                const int nbh = item_bh(jn, &nqb);
+                dma_q(item_rsrc(src.q, nbh), (nqb * NW + wave) * 32);
+            }
+            dma_next(pslot);
+            pslot = pslot + 1 == R ? 0 : pslot + 1;
+
+            if (active) {
+                const unsigned char* Kb = smem + slot * G::SLOT;
+                const unsigned kb_lds = smem_lds + (unsigned)(slot * G::SLOT);
+                f32x16 s;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(Kb + kro[ks]);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                }
+                // V^T fragments by ds_read_b64_tr_b16 (inline asm: through the builtin the compiler orders every such
+                // read behind vmcnt(0)), issued now and waited for before the PV products
+                short4v vl[G::DB][2][2];
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d) {
+                        const unsigned va = kb_lds + vro + (unsigned)(16 * sk * G::VROW + d * 64);
+                        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                                     : "=&v"(vl[d][sk][0]), "=&v"(vl[d][sk][1])
+                                     : "v"(va), "n"(8 * G::VROW)
+                                     : "memory");
+                    }
+                const int key0 = p * 32;
+                if (key0 + 32 > N) {  // wave-uniform: only the last tile of the sequence
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                        if (key >= N) s[e] = -INFINITY;
+                    }
+                }
+                float mx = s[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
+                mx = max_across_halves(mx);
+                const float m_new = fmaxf(m_run, mx * scale_log2e);
+                if (__any(m_new > m_run)) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    s[e] = __builtin_amdgcn_exp2f(s[e] * scale_log2e - m_run);
+                    psum += s[e];
+                }
+                l_run += psum;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d) {
+                        asm volatile("" : "+v"(vl[d][sk][0]), "+v"(vl[d][sk][1]));
+                    }
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    const bf16x8 pb = pack8r(s, sk);
+#pragma unroll
+                    for (int d = 0; d < G::DB; ++d) {
+                        const short8v both = __builtin_shufflevector(vl[d][sk][0], vl[d][sk][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pb, o[d], 0, 0, 0);
+                    }
+                }
+            }
+            slot = slot + 1 == R ? 0 : slot + 1;
+        }
+
+        // ---- item finished: ST stores per active wave, never waited for explicitly
+        if (active) {
+            const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+            const float inv = 1.0f / l_tot;
+            const int b = bh / H, h = bh - b * H;
+            if constexpr (LSE) {
+                if (hi == 0 && q0 + r < N) lse[(size_t)bh * N + q0 + r] = m_run + log2f(l_tot);
+            }
+            if (q0 + r < N) {
+                bf16_t* op = out + ((size_t)b * N + q0 + r) * D + (size_t)h * DH;
+#pragma unroll
+                for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        if (d * 32 + 8 * g4 < DH) {  // (DH % 8 == 0: the lane halves' 4-element pieces are both in or both out)
+                            const int d0 = d * 32 + 8 * g4 + 4 * hi;
+                            bf16x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[d][g4 * 4 + e] * inv);
+                            *(bf16x4*)(op + d0) = v;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+            m_run = -INFINITY;
+            l_run = 0.f;
+        }
+        prev_active = active;
+        if (j + 1 < nmy) {
+            bh = item_bh(j + 1, &qb);
+            q0 = (qb * NW + wave) * 32;
+        }
+    }
+    wait_vm<0>();  // the dummy DMAs of the tail must land before the LDS is released
+}
+
+template <int DH, int R>
+int launch_ring(const void* qkv, void* out, float* lse, int batch, int N, int H, hipStream_t stream) {
+    using G = RingGeo<DH>;
+    constexpr int LDS = R * G::SLOT + NW * G::QSLOT;
+    const int qblocks = ceil_div(ceil_div(N, 32), NW);
+    const long nitems = (long)batch * H * qblocks;
+    VIT_REQUIRE(nitems < (1L << 31), "attention: too many (batch, head, query block) items");
+    VIT_REQUIRE((long)N * 3 * H * DH * 2 < (1L << 31), "attention: one image's qkv rows exceed 2 GiB");
+    static int resident = 0;
+    if (resident == 0) {
+        int dev, cus, per_cu = 0;
+        VIT_CHECK_HIP(hipGetDevice(&dev));
+        VIT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)attention_ring_kernel<DH, R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)attention_ring_kernel<DH, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        VIT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)attention_ring_kernel<DH, R, false>, NW * 64, LDS));
+        resident = cus * (per_cu > 0 ? per_cu : 1);
+    }
+    const int grid = nitems < resident ? (int)nitems : resident;
+    const float scale_log2e = LOG2E / sqrtf((float)DH);
+    const int D = H * DH;
+    const unsigned char* p = (const unsigned char*)qkv;
+    RingSrc src{p, p + (size_t)D * 2, p + (size_t)2 * D * 2, (long)N * 3 * D * 2, (long)DH * 2, 3 * D * 2};
+    if (lse)
+        hipLaunchKernelGGL((attention_ring_kernel<DH, R, true>), dim3(grid), dim3(NW * 64), LDS, stream, src, (bf16_t*)out, lse, N, H,
+                           (int)nitems, qblocks, scale_log2e);
+    else
+        hipLaunchKernelGGL((attention_ring_kernel<DH, R, false>), dim3(grid), dim3(NW * 64), LDS, stream, src, (bf16_t*)out, lse, N, H,
+                           (int)nitems, qblocks, scale_log2e);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+// Ring depth for head_dim 80: 3 slots + 8 Q slots = 78.5 KiB, two workgroups per CU, the DMA two tiles ahead. Measured
+// at batch 32 x 1025 tokens x 16 heads: depth 3 / 5 / 8 = 360 / 365 / 362 us (depth does not matter once the DMA is one
+// tile ahead; two workgroups per CU shorten the tail at small batch: 111 vs 115 us at batch 8).
+constexpr int kRing80 = 3;
+constexpr int kRingMinTokens = 193;  // shorter sequences keep attention.hip's staged kernel (few tiles per item: the ring never fills)
+
+}  // namespace
+
+// head_dim 80, bf16, at least R-1 key tiles per item (the counted waits assume the stores and Q loads of one item
+// boundary have left the window before the next boundary)
+bool attention_ring_eligible(int N, int head_dim) {
+    static_assert(kRingMinTokens > 32 * (kRing80 - 1), "an item must span at least R-1 key tiles");
+    return head_dim == 80 && N >= kRingMinTokens;
+}
+
+int launch_attention_ring(const void* qkv, void* out, float* lse, int batch, int N, int H, int head_dim, hipStream_t stream) {
+    VIT_REQUIRE(attention_ring_eligible(N, head_dim), "attention ring: head_dim %d / N %d not eligible", head_dim, N);
+    return launch_ring<80, kRing80>(qkv, out, lse, batch, N, H, stream);
+}
