@@ -6,6 +6,7 @@
 #include <type_traits>
 #include "../vit_amd/csrc/gemm_bf16.hip"
 #include "../vit_amd/csrc/gemm_bf16_8p.hip"
+#include "gemm4w_lab.hip"
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -197,6 +198,15 @@ int main(int argc, char** argv) {
         vars.push_back({"shipped", [&](bf16_t* C) { launch_gemm_bf16_generic(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, nullptr, st); }});
         vars.push_back({"ring<2,4,4>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<2, 4, 4, VIT_EPI_GELU>(Q, st) : lab::launch_ring<2, 4, 4, VIT_EPI_BIAS>(Q, st); }});
         vars.push_back({"g8p", [&](bf16_t* C) { launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); }});
+        if (sh.epi == VIT_EPI_BIAS || sh.epi == VIT_EPI_GELU) {
+            vars.push_back({"g4w", [&](bf16_t* C) { launch_gemm_bf16_4w(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); }});
+            vars.push_back({"ns4w", [&](bf16_t* C) { g4_dbg = 1; launch_gemm_bf16_4w(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); g4_dbg = 0; }});
+            if (sh.epi == VIT_EPI_BIAS)
+                for (int v : {1, 2, 3, 4, 5, 6, 7, 8}) {
+                    static const char* nm[] = {"", "4w_nodma", "4w_nobar", "4w_nodmabar", "4w_nords", "4w_nodma_rds", "4w_nords_bar", "4w_mfmaonly", "4w_nomfma"};
+                    vars.push_back({nm[v], [&, v](bf16_t* C) { g4_dbg = 1 | (v << 1); launch_gemm_bf16_4w(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); g4_dbg = 0; }});
+                }
+        }
         // folded-LayerNorm epilogue (GemmExt::ln_stats): bias / activation shapes only; the statistics are arbitrary
         // numbers (timing), so this variant is reported as a mismatch against "shipped"
         static float *lnst = nullptr, *lnc = nullptr;
