@@ -64,12 +64,14 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
 }
 
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool LSE>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_dh64_kernel(
     const AttnSrc src, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H, int nitems, int qblocks,
     float scale_log2e) {
-    constexpr int ST = 8 + (LSE ? 1 : 0);  // vector-memory stores an active wave issues per item
+    constexpr int ST = 4 + (LSE ? 1 : 0);  // vector-memory stores an active wave issues per item
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * SLOT + NW * QSLOT];
 
     const unsigned smem_lds = (unsigned)(uintptr_t)LDS_PTR(smem);  // LDS byte address of the ring
@@ -304,18 +306,36 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             if constexpr (LSE) {
                 if (hi == 0 && q0 + r < N) lse[(size_t)bh * N + q0 + r] = m_run + log2f(l_tot);
             }
-            if (q0 + r < N) {
-                bf16_t* op = out + ((size_t)b * N + q0 + r) * D + (size_t)h * DH;
+            {
+                // The lane halves trade 8-byte pieces (v_permlane32_swap) so that every lane holds 8 consecutive head
+                // dims: 16-byte stores, four per item instead of eight, each row's 128 bytes touched by four instructions.
+                bf16_t* op = out + ((size_t)b * N + q0 + r) * D + (size_t)h * DH + 8 * hi;
+                const bool row_ok = q0 + r < N;
 #pragma unroll
-                for (int d = 0; d < 2; ++d)
+                for (int d = 0; d < 2; ++d) {
+                    unsigned w[4][2];
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const int d0 = d * 32 + 8 * g4 + 4 * hi;
                         bf16x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[d][g4 * 4 + e] * inv);
-                        *(bf16x4*)(op + d0) = v;
+                        const u32x2 u = __builtin_bit_cast(u32x2, v);
+                        w[g4][0] = u[0];
+                        w[g4][1] = u[1];
                     }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        // lanes < 32 keep piece 2pr and receive their partner's; lanes >= 32 keep piece 2pr+1
+                        u32x4 pk;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(w[2 * pr][k], w[2 * pr + 1][k], false, false);
+                            pk[k] = (unsigned)sw[0];
+                            pk[2 + k] = (unsigned)sw[1];
+                        }
+                        if (row_ok) *(u32x4*)(op + d * 32 + 16 * pr) = pk;
+                    }
+                }
             }
 #pragma unroll
             for (int d = 0; d < 2; ++d)

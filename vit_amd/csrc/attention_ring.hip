@@ -18,6 +18,8 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int NW = 8;  // waves per workgroup
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int DH>
 struct RingGeo {
@@ -32,7 +34,7 @@ struct RingGeo {
     static constexpr int SLOT = KTILE + VTILE;     // one ring slot: K rows then V rows of 32 keys
     static constexpr int QSLOT = 32 * KROW;        // one wave's 32 query rows
     static constexpr int NQ = 8;                   // Q DMA pieces per wave and item (4 rows each)
-    static constexpr int ST = (DH + 7) / 8;        // output store instructions of an active wave per item (8 bytes per lane each)
+    static constexpr int ST = DH / 16;             // output store instructions of an active wave per item (16 bytes per lane each)
     static_assert(DH % 16 == 0 && 4 * KCH <= 64 && 4 * VCH <= 64, "a four-row piece must fit one wave instruction");
 };
 
@@ -274,20 +276,37 @@ __global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc s
             if constexpr (LSE) {
                 if (hi == 0 && q0 + r < N) lse[(size_t)bh * N + q0 + r] = m_run + log2f(l_tot);
             }
-            if (q0 + r < N) {
-                bf16_t* op = out + ((size_t)b * N + q0 + r) * D + (size_t)h * DH;
+            {
+                // The lane halves trade 8-byte pieces (v_permlane32_swap) so that every lane holds 8 consecutive head
+                // dims: 16-byte stores (DH % 16 == 0: a pair of pieces is in or out as a whole)
+                bf16_t* op = out + ((size_t)b * N + q0 + r) * D + (size_t)h * DH + 8 * hi;
+                const bool row_ok = q0 + r < N;
 #pragma unroll
-                for (int d = 0; d < G::DB; ++d)
+                for (int d = 0; d < G::DB; ++d) {
+                    unsigned w[4][2];
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        if (d * 32 + 8 * g4 < DH) {  // (DH % 8 == 0: the lane halves' 4-element pieces are both in or both out)
-                            const int d0 = d * 32 + 8 * g4 + 4 * hi;
-                            bf16x4 v;
+                        bf16x4 v;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[d][g4 * 4 + e] * inv);
-                            *(bf16x4*)(op + d0) = v;
+                        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[d][g4 * 4 + e] * inv);
+                        const u32x2 u = __builtin_bit_cast(u32x2, v);
+                        w[g4][0] = u[0];
+                        w[g4][1] = u[1];
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        if (d * 32 + 16 * pr < DH) {
+                            u32x4 pk;
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const auto sw = __builtin_amdgcn_permlane32_swap(w[2 * pr][k], w[2 * pr + 1][k], false, false);
+                                pk[k] = (unsigned)sw[0];
+                                pk[2 + k] = (unsigned)sw[1];
+                            }
+                            if (row_ok) *(u32x4*)(op + d * 32 + 16 * pr) = pk;
                         }
                     }
+                }
             }
 #pragma unroll
             for (int d = 0; d < G::DB; ++d)

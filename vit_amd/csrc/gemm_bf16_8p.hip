@@ -44,12 +44,16 @@
 //    in 2.3 us per CU, the natural 16-rows-x-64-B MFMA shape needs 4.5 us.
 #include "vit_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace g8 {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef G8_STORE_AUX
+#define G8_STORE_AUX 2  // cache policy of the output stores: nt (streamed through L2, not retained)
+#endif
 constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
 constexpr int HALF_BYTES = 128 * BK * 2;        // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;       // 64 KiB: A_h0, A_h1, B_h0, B_h1
@@ -81,6 +85,7 @@ struct PParams {
     int M, N, K;     // K = reduction length of ONE split
     int lda;         // row pitch (elements) of A and W: K * splits
     int NT;      // tiles along N
+    int MT, GC;  // tiles along M; column-group width of the tile order (see tile_coords)
     int TMN;     // output tiles per split = ceil(M/256) * NT
     int T;       // total work items = TMN * splits; split s writes the fp32 slab C + s*M*N (OUTM 1)
     // LNF (template flag): LayerNorm folded in -- epilogue value = rstd * acc - (mean * rstd) * ln_c + bias
@@ -124,11 +129,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     const int i = lane & 15, q = lane >> 4;
     const int p = tid & 7;
 
+    // Tile order inside a split: column groups of GC tile columns, and inside a group mt-major. The 32 workgroups of
+    // an XCD walk consecutive tiles, i.e. ~32 / GC tile rows x GC tile columns at a time: with GC chosen so that the
+    // group's W panels (GC x 256 x K) stay in the XCD's 4 MiB L2 beside the A panels passing through, W is fetched
+    // from beyond L2 once per group instead of once per round (GC >= NT: plain mt-major order).
+    auto tile_coords = [&](int t2, int* mt, int* nt) {
+        const int per_group = P.MT * P.GC;
+        const int g = t2 / per_group, rem = t2 - g * per_group;
+        const int left = P.NT - g * P.GC;
+        const int gc = left < P.GC ? left : P.GC;
+        const int m = rem / gc;
+        *mt = m;
+        *nt = g * P.GC + rem - m * gc;
+    };
     unsigned a_of[2][2], w_of[2][2];          // per-lane byte offsets from the tile's first A / W row
     __amdgpu_buffer_rsrc_t Ar, Wr;            // wave-uniform buffer resources based at those rows
     auto set_tile = [&](int tile_idx) {   // staging offsets / bases for a tile
         const int sp = tile_idx / P.TMN, t2 = tile_idx - sp * P.TMN;
-        const int mt = t2 / P.NT, nt = t2 - mt * P.NT;
+        int mt, nt;
+        tile_coords(t2, &mt, &nt);
         const int m0 = mt * BM, n0 = nt * BN;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -301,7 +320,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         const bool has_next = nlt < cnt;
         next_tile = has_next ? start + nlt : cur_tile;  // no next tile: harmless re-prefetch of this one
         if constexpr (LNF) {
-            const int t2 = cur_tile % P.TMN, m0 = (t2 / P.NT) * BM;
+            int mt, nt;
+            tile_coords(cur_tile % P.TMN, &mt, &nt);
+            const int m0 = mt * BM;
             const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
             Sr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.ln_stats + (size_t)m0 * 2), 0, (unsigned)rows_here * 8u, 0x00020000);
         }
@@ -331,7 +352,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             // dropped by the hardware range check; lanes whose columns are >= N get an offset that
             // is always out of range. No branches.
             const int sp = cur_tile / P.TMN, t2 = cur_tile - sp * P.TMN;
-            const int mt = t2 / P.NT, nt = t2 - mt * P.NT;
+            int mt, nt;
+            tile_coords(t2, &mt, &nt);
             const int m0 = mt * BM, n0 = nt * BN;
             const int nb = n0 + wc * 64 + 4 * i;
             const bool col_ok = nb < P.N;  // N % 8 == 0: 4 columns all in or all out
@@ -473,7 +495,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                             bf16x4 ov;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, G8_STORE_AUX);
                         }
                     }
             }  // !EPI_PATCH
@@ -493,6 +515,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
 #endif
     G8_WAIT_VM(0);  // the dummy prefetch of the last tile must land before the LDS is released
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance team 1's extra barrier
+}
+
+// Column-group width of the tile order (PParams::GC). Lab switch VIT_AMD_GEMM_GC: 0 = plain order, n = groups of n.
+inline int group_cols(int NT, int K) {
+    static const int forced = getenv("VIT_AMD_GEMM_GC") ? atoi(getenv("VIT_AMD_GEMM_GC")) : -1;
+    if (forced == 0) return NT;
+    if (forced > 0) return forced < NT ? forced : NT;
+    if (NT <= 6) return NT;
+    const int groups = (NT + 5) / 6;  // about six columns each: 32 workgroups of an XCD cover ~5.3 x 6 tiles, the squarest cut
+    return (NT + groups - 1) / groups;
 }
 
 template <int EPI, int OUTM, bool LNF = false>
@@ -548,7 +580,9 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
     VIT_REQUIRE(splits == 1 || (ext->out_f32 && ext->slabs != nullptr), "gemm8p: split-K needs fp32 output and a slab workspace");
     P.M = M; P.N = N; P.K = K / splits; P.lda = K;
     P.NT = ceil_div(N, g8::BN);
-    P.TMN = ceil_div(M, g8::BM) * P.NT;
+    P.MT = ceil_div(M, g8::BM);
+    P.GC = g8::group_cols(P.NT, K / splits);
+    P.TMN = P.MT * P.NT;
     P.T = P.TMN * splits;
     if (splits > 1) P.C = (bf16_t*)ext->slabs;
 #ifdef G8_LAB
@@ -602,7 +636,9 @@ int launch_gemm_bf16_8p_patch(const void* pixels, const void* W, const float* bi
     q.A = (const bf16_t*)pixels; q.W = (const bf16_t*)W; q.bias = bias; q.C = (bf16_t*)C; q.pos = pos;
     q.M = M; q.N = N; q.K = K; q.lda = K;
     q.NT = ceil_div(N, g8::BN);
-    q.TMN = ceil_div(M, g8::BM) * q.NT;
+    q.MT = ceil_div(M, g8::BM);
+    q.GC = q.NT;
+    q.TMN = q.MT * q.NT;
     q.T = q.TMN;
     q.np = g->grid * g->grid; q.grid = g->grid; q.patch = P; q.image = g->image;
     q.img_bytes = (unsigned)g->channels * g->image * g->image * 2u;
@@ -638,7 +674,9 @@ int launch_gemm_bf16_8p_patch_dense(const void* A, const void* W, const float* b
     q.A = (const bf16_t*)A; q.W = (const bf16_t*)W; q.bias = bias; q.C = (bf16_t*)C; q.pos = pos;
     q.M = M; q.N = N; q.K = K; q.lda = K;
     q.NT = ceil_div(N, g8::BN);
-    q.TMN = ceil_div(M, g8::BM) * q.NT;
+    q.MT = ceil_div(M, g8::BM);
+    q.GC = q.NT;
+    q.TMN = q.MT * q.NT;
     q.T = q.TMN;
     q.np = g->grid * g->grid; q.grid = g->grid; q.patch = g->patch; q.image = g->image;
 #ifdef G8_LAB
