@@ -70,6 +70,32 @@ __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned l
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, (int)lane_off, uni_off, 0, 0);
 }
 
+// Folded LayerNorm: read n of the epilogue brings two rows' (mean * rstd, rstd) of the lane's rows
+// (ha = n >> 3, mi = (n >> 1) & 3, row pair n & 1) into slot n % 3 of a three-deep window.
+template <int N>
+__device__ __forceinline__ void st_read(f32x4 (&spw)[3], unsigned st_lds) {
+    constexpr int off = ((N >> 3) * 128 + ((N >> 1) & 3) * 16 + (N & 1) * 2) * 8;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(spw[N % 3]) : "v"(st_lds), "n"(off) : "memory");
+}
+__device__ __forceinline__ void st_read_sw(int n, f32x4 (&spw)[3], unsigned st_lds) {  // n is a constant after unrolling
+    switch (n) {
+        case 2: st_read<2>(spw, st_lds); break;
+        case 3: st_read<3>(spw, st_lds); break;
+        case 4: st_read<4>(spw, st_lds); break;
+        case 5: st_read<5>(spw, st_lds); break;
+        case 6: st_read<6>(spw, st_lds); break;
+        case 7: st_read<7>(spw, st_lds); break;
+        case 8: st_read<8>(spw, st_lds); break;
+        case 9: st_read<9>(spw, st_lds); break;
+        case 10: st_read<10>(spw, st_lds); break;
+        case 11: st_read<11>(spw, st_lds); break;
+        case 12: st_read<12>(spw, st_lds); break;
+        case 13: st_read<13>(spw, st_lds); break;
+        case 14: st_read<14>(spw, st_lds); break;
+        case 15: st_read<15>(spw, st_lds); break;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Persistent form: one workgroup per CU walks a list of output tiles. The K-tile stream is
 // continuous across tile boundaries (the last two K-tiles of a tile already stage the first
@@ -258,6 +284,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     // B_h1/A_h1 were retired before the loop / at the start of the previous epilogue).
     int next_tile = 0;
     __amdgpu_buffer_rsrc_t Sr = Ar;  // LNF: this tile's rows of ln_stats (rows >= M read as 0)
+    __amdgpu_buffer_rsrc_t BLr = Ar; // this tile's 256 bias values (waves 0-3) / ln_c values (waves 4-7); columns >= N read as 0
+    // bias / ln_c travel through LDS (not in the residual / gradient epilogues: their 64 prefetch registers leave no room,
+    // the extra spills cost more than the wait: o_proj + residual 76 -> 78.5 us)
+    constexpr bool SIDE = (EPI == VIT_EPI_BIAS || EPI == VIT_EPI_GELU || EPI == VIT_EPI_QUICK_GELU);
     auto ktile = [&](auto BUFC, auto MODEC, auto FIRSTC, int t) {
         constexpr int BUF = decltype(BUFC)::value, MODE = decltype(MODEC)::value;
         constexpr bool FIRST = decltype(FIRSTC)::value;
@@ -268,6 +298,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         // from the epilogue, where the waves read each other's pieces.
         if constexpr (LNF && MODE == 2)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(Sr, LDS_PTR(smem + LDS_BYTES + wave * 256), 4, lane * 4, wave * 256, 0, 0);
+        // The tile's bias (and ln_c) values take the same route, 1 KiB each behind the statistics: a global load in the
+        // epilogue is the youngest vector-memory operation there, so the wait for it (vmcnt(0)) also waits for the
+        // next tile's staged K-tiles, with every store of the epilogue queued behind that.
+        if constexpr (SIDE && MODE == 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(BLr, LDS_PTR(smem + LDS_BYTES + 2048 + wave * 256), 4, lane * 4, (wave & 3) * 256, 0, 0);
         // ph1: (A0,B0)
         read_b(BUF, 0);
         read_a(BUF, 0);
@@ -319,12 +354,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         const int nlt = lt + gx;
         const bool has_next = nlt < cnt;
         next_tile = has_next ? start + nlt : cur_tile;  // no next tile: harmless re-prefetch of this one
-        if constexpr (LNF) {
+        if constexpr (LNF || SIDE) {
             int mt, nt;
             tile_coords(cur_tile % P.TMN, &mt, &nt);
-            const int m0 = mt * BM;
-            const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
-            Sr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.ln_stats + (size_t)m0 * 2), 0, (unsigned)rows_here * 8u, 0x00020000);
+            const int m0 = mt * BM, n0 = nt * BN;
+            if constexpr (LNF) {
+                const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
+                Sr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.ln_stats + (size_t)m0 * 2), 0, (unsigned)rows_here * 8u, 0x00020000);
+            }
+            if constexpr (SIDE) {
+                const float* side = wave < 4 ? P.bias : (LNF ? P.ln_c : nullptr);
+                const int cols_here = (P.N - n0 < BN) ? P.N - n0 : BN;
+                // no bias: zero records, every lane out of range, the DMA writes zeros
+                BLr = __builtin_amdgcn_make_buffer_rsrc((void*)(side ? side + n0 : P.ln_stats), 0, side ? (unsigned)cols_here * 4u : 0u, 0x00020000);
+            }
         }
         G8_STAMP(0, tcount == 1);
         ktile(I0{}, I0{}, BT{}, 0);
@@ -414,28 +457,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             if constexpr (OUTM == 2)
                 Pr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.Cpre + (size_t)m0 * P.N), 0, span, 0x00020000);
             const unsigned voff0 = col_ok ? (unsigned)((wr * 64 + 4 * q) * P.N + nb) * 2u : 0x80000000u;
-            float bias[4] = {0.f, 0.f, 0.f, 0.f};
-            if (P.bias != nullptr && col_ok) {
-                const float4 b0 = *(const float4*)(P.bias + nb);
-                bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+            // bias, ln_c (column sums of the folded weight) and the tile's (mean * rstd, rstd) are in LDS behind the ring
+            // (DMA of the last K-tile), read by inline asm (a C++ LDS load behind an LDS-DMA draws a vmcnt(0)). The
+            // statistics are read two rows at a time, two reads ahead of their use (all 32 rows' pairs up front held 64
+            // more VGPRs through the epilogue and cost 7-8 us per launch; one read ahead left the LDS latency exposed
+            // sixteen times per tile, 17 us per launch of fc1 + GELU).
+            const unsigned side_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + (unsigned)(LDS_BYTES + 2048 + (wc * 64 + 4 * i) * 4);
+            const unsigned st_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + (unsigned)(LDS_BYTES + (wr * 64 + 4 * q) * 8);
+            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f}, lnc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 spw[3];
+            if constexpr (!SIDE) {
+                if (P.bias != nullptr && col_ok) bias4 = *(const f32x4*)(P.bias + nb);
+            } else {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bias4) : "v"(side_lds) : "memory");
             }
-            // LayerNorm folded in: the tile's (mean * rstd, rstd) are in LDS behind the ring (DMA of the last K-tile),
-            // read two rows at a time right where they are used (fetching all 32 rows' pairs up front held 64 more
-            // VGPRs through the epilogue and cost 7-8 us per launch); and the column sums of the folded weight
-            float lnc[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (LNF) {
-                if (col_ok) {
-                    const float4 c4 = *(const float4*)(P.ln_c + nb);
-                    lnc[0] = c4.x; lnc[1] = c4.y; lnc[2] = c4.z; lnc[3] = c4.w;
-                }
+            if constexpr (!SIDE) {
+            } else if constexpr (LNF) {
+                asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(lnc4) : "v"(side_lds) : "memory");
+                st_read<0>(spw, st_lds);
+                st_read<1>(spw, st_lds);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bias4), "+v"(lnc4)::"memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias4)::"memory");
             }
+            const float bias[4] = {bias4[0], bias4[1], bias4[2], bias4[3]};
+            const float lnc[4] = {lnc4[0], lnc4[1], lnc4[2], lnc4[3]};
             // residual / aux tile: all 32 loads are issued up front into the (now dead) fragment registers
             u32x2 rres[32];
             if constexpr (USES_RES) {
 #pragma unroll
                 for (int s = 0; s < 32; ++s) {
                     const unsigned voff = voff0 + (unsigned)(((s >> 4) * 128 + ((s >> 2) & 3) * 16 + (s & 3)) * P.N) * 2u;
-                    rres[s] = __builtin_amdgcn_raw_buffer_load_b64(Rr, (int)voff, 0, 0);
+                    rres[s] = __builtin_amdgcn_raw_buffer_load_b64(Rr, (int)voff, 0, 0);  // (an nt hint here costs 0.7 % per forward: the rows were just written by the previous kernel)
                 }
             }
 #pragma unroll
@@ -447,8 +500,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                         const unsigned voff = voff0 + (unsigned)((ha * 128 + mi * 16 + j) * P.N) * 2u;
                         float v[4];
                         if constexpr (LNF) {
-                            // two rows' (mean * rstd, rstd)
-                            const f32x4 sp = *(const f32x4*)(smem + LDS_BYTES + (ha * 128 + wr * 64 + mi * 16 + 4 * q + (j >> 1) * 2) * 8);
+                            // two rows' (mean * rstd, rstd): read n, issued two reads ago
+                            const int n = ha * 8 + mi * 2 + (j >> 1);
+                            if ((j & 1) == 0) {
+                                if (n + 2 < 16) {
+                                    // (the index must be a constant expression: spelled out per value of n)
+                                    st_read_sw(n + 2, spw, st_lds);
+                                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(spw[n % 3])::"memory");
+                                } else if (n + 2 == 16) {
+                                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(spw[n % 3])::"memory");
+                                } else {
+                                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(spw[n % 3])::"memory");
+                                }
+                            }
+                            const f32x4 sp = spw[n % 3];
                             const float mr = (j & 1) ? sp[2] : sp[0], rs = (j & 1) ? sp[3] : sp[1];
                             // two packed fmas per column pair (same bits as the fmaf chain of the generic kernel)
 #pragma unroll
@@ -469,7 +534,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                             bf16x4 pv;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) pv[e] = (bf16_t)v[e];
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pv), Pr, (int)voff, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pv), Pr, (int)voff, 0, G8_STORE_AUX);
                         }
                         if constexpr (EPI == VIT_EPI_GELU) {
                             const f32x2 g0 = act_gelu_pk(f32x2{v[0], v[1]}), g1 = act_gelu_pk(f32x2{v[2], v[3]});
@@ -490,7 +555,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                         if constexpr (OUTM == 1) {
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
                                                                          __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])},
-                                                                   Cr, (int)(voff * 2u), 0, 0);
+                                                                   Cr, (int)(voff * 2u), 0, G8_STORE_AUX);
                         } else {
                             bf16x4 ov;
 #pragma unroll
@@ -532,11 +597,11 @@ int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
     auto kern = gemm8p_persist_kernel<EPI, OUTM, LNF>;
     static bool attr_set = false;
     if (!attr_set) {
-        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (LNF ? 2048 : 0)));
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 4096));
         attr_set = true;
     }
     const int G = P.T < ncu ? P.T : ncu;
-    hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), LDS_BYTES + (LNF ? 2048 : 0), stream, P);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), LDS_BYTES + 4096, stream, P);
     VIT_CHECK_HIP(hipGetLastError());
     return VIT_OK;
 }
