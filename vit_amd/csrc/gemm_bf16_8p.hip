@@ -285,9 +285,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     int next_tile = 0;
     __amdgpu_buffer_rsrc_t Sr = Ar;  // LNF: this tile's rows of ln_stats (rows >= M read as 0)
     __amdgpu_buffer_rsrc_t BLr = Ar; // this tile's 256 bias values (waves 0-3) / ln_c values (waves 4-7); columns >= N read as 0
-    // bias / ln_c travel through LDS (not in the residual / gradient epilogues: their 64 prefetch registers leave no room,
-    // the extra spills cost more than the wait: o_proj + residual 76 -> 78.5 us)
-    constexpr bool SIDE = (EPI == VIT_EPI_BIAS || EPI == VIT_EPI_GELU || EPI == VIT_EPI_QUICK_GELU);
+    constexpr bool SIDE = (EPI != EPI_PATCH && EPI != EPI_PATCH_DENSE);  // bias / ln_c travel through LDS
     auto ktile = [&](auto BUFC, auto MODEC, auto FIRSTC, int t) {
         constexpr int BUF = decltype(BUFC)::value, MODE = decltype(MODEC)::value;
         constexpr bool FIRST = decltype(FIRSTC)::value;
@@ -482,14 +480,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             }
             const float bias[4] = {bias4[0], bias4[1], bias4[2], bias4[3]};
             const float lnc[4] = {lnc4[0], lnc4[1], lnc4[2], lnc4[3]};
-            // residual / aux tile: all 32 loads are issued up front into the (now dead) fragment registers
+            // residual / aux tile: the first RW of the lane's 32 row loads are issued up front into the (now dead) fragment
+            // registers, load s + RW when row s has been consumed. (All 32 up front: 64 registers, and the spills they
+            // forced were reloaded behind a vmcnt(0) at the top of every epilogue.)
+            constexpr int RW = (EPI == VIT_EPI_RESIDUAL) ? 24 : 16;
             u32x2 rres[32];
+            auto res_load = [&](int s) {
+                const unsigned voff = voff0 + (unsigned)(((s >> 4) * 128 + ((s >> 2) & 3) * 16 + (s & 3)) * P.N) * 2u;
+                return __builtin_amdgcn_raw_buffer_load_b64(Rr, (int)voff, 0, 0);  // (an nt hint here costs 0.7 % per forward: the rows were just written by the previous kernel)
+            };
             if constexpr (USES_RES) {
 #pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    const unsigned voff = voff0 + (unsigned)(((s >> 4) * 128 + ((s >> 2) & 3) * 16 + (s & 3)) * P.N) * 2u;
-                    rres[s] = __builtin_amdgcn_raw_buffer_load_b64(Rr, (int)voff, 0, 0);  // (an nt hint here costs 0.7 % per forward: the rows were just written by the previous kernel)
-                }
+                for (int s = 0; s < RW; ++s) rres[s] = res_load(s);
             }
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
@@ -561,6 +563,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
 #pragma unroll
                             for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, G8_STORE_AUX);
+                        }
+                        if constexpr (USES_RES) {
+                            const int sn = ha * 16 + mi * 4 + j + RW;
+                            if (sn < 32) {
+                                __builtin_amdgcn_sched_barrier(0);  // not hoisted: the window is what keeps the registers down
+                                rres[sn] = res_load(sn);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
             }  // !EPI_PATCH
