@@ -248,11 +248,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
                 const int key0 = p * 32;
                 if (key0 + 32 > N) {  // wave-uniform: only the last tile of the sequence
+                    // (the limit is made opaque here: hoisted out of the loops, the 16 lane masks live in 32 SGPRs and
+                    // push the loop's own scalars into spill lanes)
+                    int lim = N - key0 - 4 * hi;
+                    asm volatile("" : "+v"(lim));
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                        if (key >= N) s[e] = -INFINITY;
-                    }
+                    for (int e = 0; e < 16; ++e)
+                        if ((e & 3) + 8 * (e >> 2) >= lim) s[e] = -INFINITY;
                 }
 #if ATTN_VAR != 1
                 float mx = s[0];
