@@ -1,0 +1,77 @@
+"""GPU tests of the library's environment switches: each switch is read once per process, so every case runs a
+small script in a child process (the child is started BEFORE it touches the GPU; the parent of this test never execs).
+
+* VIT_AMD_GEMM_GC: the column-grouped tile order of the persistent GEMM only changes WHICH workgroup computes a tile
+  and when -- the output must be bit-identical to the plain mt-major order, for every epilogue that kernel has.
+* VIT_AMD_ATTN_RING: head_dim-80 attention on the LDS-DMA ring kernel against the staged kernel it replaces (both
+  fp32 online softmax over 32-key tiles; checked to bf16 tolerance, and both against the oracle in test_gpu_kernels).
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+GEMM_SCRIPT = r"""
+import hashlib, json, sys, torch
+from vit_amd import ops, synth
+dev = "cuda:0"
+out = {}
+# N = 2304 (9 tile columns -> groups of 5 + 4) and N = 3072 (12 -> 6 + 6), ragged M, K % 128 == 0 and
+# M * N >= 64 tiles: the persistent kernel takes both
+for (m, n, k) in [(2000, 2304, 256), (1400, 3072, 384)]:
+    x = synth.normal((m, k), 3, "x").to(dev, torch.bfloat16)
+    w = synth.normal((n, k), 4, "w", std=0.05).to(dev, torch.bfloat16)
+    b = synth.normal((n,), 5, "b", std=0.1).to(dev)
+    r = synth.normal((m, n), 6, "r").to(dev, torch.bfloat16)
+    for epi in (None, "gelu", "quick_gelu"):
+        y = ops.linear(x, w, b, activation=epi)
+        out[f"{m}x{n}x{k}:{epi}"] = hashlib.sha256(y.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
+    y = ops.linear(x, w, b, residual=r)
+    out[f"{m}x{n}x{k}:res"] = hashlib.sha256(y.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
+print(json.dumps(out))
+"""
+
+ATTN_SCRIPT = r"""
+import json, sys, torch
+from vit_amd import ops, synth
+dev = "cuda:0"
+qkv = synth.normal((2, 257, 3 * 4 * 80), 11, "qkv").to(dev, torch.bfloat16)
+o = ops.attention(qkv, 4).float().cpu()
+torch.save(o, sys.argv[1])
+print(json.dumps({"ok": bool(torch.isfinite(o).all())}))
+"""
+
+
+def run_child(script, env_extra, *args):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, "-c", script, *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_grouped_tile_order_gives_the_same_bits_as_plain_order():
+    plain = run_child(GEMM_SCRIPT, {"VIT_AMD_GEMM_GC": "0"})
+    grouped = run_child(GEMM_SCRIPT, {"VIT_AMD_GEMM_GC": "-1"})   # the default policy
+    narrow = run_child(GEMM_SCRIPT, {"VIT_AMD_GEMM_GC": "2"})
+    assert plain.keys() == grouped.keys() and len(plain) == 8
+    assert plain == grouped
+    assert plain == narrow
+
+
+def test_ring_attention_matches_staged_kernel(tmp_path):
+    import torch
+    a, b = str(tmp_path / "ring.pt"), str(tmp_path / "staged.pt")
+    assert run_child(ATTN_SCRIPT, {"VIT_AMD_ATTN_RING": "1"}, a)["ok"]
+    assert run_child(ATTN_SCRIPT, {"VIT_AMD_ATTN_RING": "0"}, b)["ok"]
+    ring, staged = torch.load(a, weights_only=True), torch.load(b, weights_only=True)
+    assert ring.shape == staged.shape == (2, 257, 320)
+    scale = staged.abs().max().item()
+    assert (ring - staged).abs().max().item() <= scale / 128  # 2 bf16 ulps of the output scale
