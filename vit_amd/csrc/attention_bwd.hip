@@ -17,6 +17,12 @@
 // Transposed operands (K^T, dO^T, Q^T) come from row-major LDS images by ds_read_b64_tr_b16.
 // S and dP are computed twice (7 instead of 5 products) -- the price of having no cross-wave
 // reduction; at N = 197 the backward is HBM/latency bound anyway (DESIGN.md "Backward").
+//
+// Round 2: the kernel is PERSISTENT (one workgroup per CU walks (batch, head, outer block) items) and the global loads
+// of the next staging unit (the next chunk of inner rows, or the next item's first chunk and outer fragments) are
+// issued into registers before the current chunk's products, so the HBM latency that the one-item-per-workgroup form
+// exposed at every item (1 workgroup per CU: nothing else to run) hides behind them. Same operations in the same
+// order per item: bit-identical results.
 #include "vit_common.h"
 #include <math.h>
 
@@ -32,6 +38,7 @@ struct BGeo {
     static constexpr int RS = DH * 2 + 16;      // row-read image stride, bytes (conflict-free ds_read_b128)
     static constexpr int TS = (DB | 1) * 64;    // tr-read image stride, bytes (odd multiple of 64)
     static constexpr int CHUNKS = DH / 8;
+    static constexpr int PIT = DH <= 64 ? 4 : 2;  // staging loads (16 bytes of each operand) a thread holds in flight per chunk
 };
 
 __device__ __forceinline__ bf16x8 pack8b(const f32x16& p, int s) {
@@ -55,8 +62,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int row0, in
 template <int DH, int MODE>
 __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                        const float* __restrict__ lse, const float* __restrict__ delta,
-                                                       bf16_t* __restrict__ dqkv, int N, int H, int IC, float scale_log2e,
-                                                       float scale) {
+                                                       bf16_t* __restrict__ dqkv, int N, int H, int IC, int blocks, int nitems,
+                                                       float scale_log2e, float scale) {
     using G = BGeo<DH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // inner-operand images: I1 = K (DQ) / Q (DKV), I2 = V (DQ) / dO (DKV)
@@ -69,78 +76,133 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwaves = blockDim.x >> 6;
+    const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
     const int r = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int D = H * DH;
     const size_t rs = (size_t)3 * D;
-    const bf16_t* qbase = qkv + (size_t)b * N * rs + (size_t)h * DH;          // q | k (+D) | v (+2D)
-    const bf16_t* dobase = dO + (size_t)b * N * D + (size_t)h * DH;
-    const float* lrow = lse + ((size_t)b * H + h) * N;
-    const float* drow = delta + ((size_t)b * H + h) * N;
-
-    // ---- outer fragments (B operands): lane&31 = outer row, 8 consecutive d of half hi per k-step
-    const int o0 = (blockIdx.y * nwaves + wave) * 32;
-    const int orow = (o0 + r < N) ? o0 + r : N - 1;
-    bf16x8 f1[G::KSTEPS], f2[G::KSTEPS];
-#pragma unroll
-    for (int ks = 0; ks < G::KSTEPS; ++ks) {
-        if constexpr (MODE == MODE_DQ) {
-            f1[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + ks * 16 + hi * 8);             // Q
-            f2[ks] = *(const bf16x8*)(dobase + (size_t)orow * D + ks * 16 + hi * 8);             // dO
-        } else {
-            f1[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + D + ks * 16 + hi * 8);         // K
-            f2[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + 2 * D + ks * 16 + hi * 8);     // V
-        }
-    }
-    float oL = 0.f, oD = 0.f;  // DQ: per-lane query constants
-    if constexpr (MODE == MODE_DQ) {
-        oL = lrow[orow];
-        oD = drow[orow];
-    }
-
-    f32x16 acc1[G::DB], acc2[G::DB];  // DQ: acc1 = dQ^T.  DKV: acc1 = dK^T, acc2 = dV^T
-#pragma unroll
-    for (int d = 0; d < G::DB; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { acc1[d][e] = 0.f; acc2[d][e] = 0.f; }
-
+    const int nchunks = (N + IC - 1) / IC;
     const int g = lane >> 4, i16 = lane & 15;
     const int tr_key = 4 * (g >> 1) + (i16 >> 2);
     const int tr_col = ((g & 1) * 16 + 4 * (i16 & 3)) * 2;
 
-    for (int ic0 = 0; ic0 < N; ic0 += IC) {
-        int nin = N - ic0;
-        nin = (nin > IC) ? IC : ((nin + 31) & ~31);
-        __syncthreads();
-        // ---- stage the inner rows (pad rows re-read the last row; they are masked below)
-        const int total = nin * G::CHUNKS;
-        for (int idx = tid; idx < total; idx += blockDim.x) {
-            const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
-            int gr = ic0 + row;
-            if (gr > N - 1) gr = N - 1;
-            bf16x8 v1, v2;
-            if constexpr (MODE == MODE_DQ) {
-                const bf16_t* p = qbase + (size_t)gr * rs + c * 8;
-                v1 = *(const bf16x8*)(p + D);       // K
-                v2 = *(const bf16x8*)(p + 2 * D);   // V
-            } else {
-                v1 = *(const bf16x8*)(qbase + (size_t)gr * rs + c * 8);      // Q
-                v2 = *(const bf16x8*)(dobase + (size_t)gr * D + c * 8);     // dO
+    // ---- staging registers of the NEXT unit
+    constexpr int PIT = G::PIT;
+    bf16x8 pv1[PIT], pv2[PIT];
+    float pL = 0.f, pD = 0.f;                    // DKV: L2 / delta of inner row tid of the chunk
+    auto item_coords = [&](int item, int* b, int* h, int* o0) {
+        const int bh = item / blocks, by = item - bh * blocks;
+        *b = bh / H;
+        *h = bh - *b * H;
+        *o0 = (by * nwaves + wave) * 32;
+    };
+    auto chunk_rows = [&](int chunk) {
+        int nin = N - chunk * IC;
+        return (nin > IC) ? IC : ((nin + 31) & ~31);
+    };
+    auto prefetch = [&](int item, int chunk) {
+        int b, h, o0;
+        item_coords(item, &b, &h, &o0);
+        const bf16_t* qbase = qkv + (size_t)b * N * rs + (size_t)h * DH;          // q | k (+D) | v (+2D)
+        const bf16_t* dobase = dO + (size_t)b * N * D + (size_t)h * DH;
+        const int ic0 = chunk * IC, total = chunk_rows(chunk) * G::CHUNKS;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int idx = tid + it * nthreads;
+            if (idx < total) {
+                const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+                int gr = ic0 + row;
+                if (gr > N - 1) gr = N - 1;  // pad rows re-read the last row; they are masked below
+                if constexpr (MODE == MODE_DQ) {
+                    const bf16_t* p = qbase + (size_t)gr * rs + c * 8;
+                    pv1[it] = *(const bf16x8*)(p + D);       // K
+                    pv2[it] = *(const bf16x8*)(p + 2 * D);   // V
+                } else {
+                    pv1[it] = *(const bf16x8*)(qbase + (size_t)gr * rs + c * 8);      // Q
+                    pv2[it] = *(const bf16x8*)(dobase + (size_t)gr * D + c * 8);     // dO
+                }
             }
-            *(bf16x8*)(R1 + (size_t)row * G::RS + c * 16) = v1;
-            *(bf16x8*)(R2 + (size_t)row * G::RS + c * 16) = v2;
-            *(bf16x8*)(T1 + (size_t)row * G::TS + c * 16) = v1;
-            if constexpr (MODE == MODE_DKV) *(bf16x8*)(T2 + (size_t)row * G::TS + c * 16) = v2;
         }
         if constexpr (MODE == MODE_DKV) {
-            for (int row = tid; row < nin; row += blockDim.x) {
-                const int gr = ic0 + row;
-                rowL[row] = gr < N ? lrow[gr] : INFINITY;  // P = exp2(.. - inf) = 0 for pad queries
-                rowD[row] = gr < N ? drow[gr] : 0.f;
+            if (tid < chunk_rows(chunk)) {
+                const int gr = ic0 + tid;
+                const size_t base = ((size_t)b * H + h) * N;
+                pL = gr < N ? lse[base + gr] : INFINITY;  // P = exp2(.. - inf) = 0 for pad queries
+                pD = gr < N ? delta[base + gr] : 0.f;
+            }
+        }
+    };
+
+    bf16x8 f1[G::KSTEPS], f2[G::KSTEPS];
+    float oL = 0.f, oD = 0.f;  // DQ: per-lane query constants
+    // outer fragments (B operands) of an item: lane&31 = outer row, 8 consecutive d of half hi per k-step. Loaded for the
+    // first item here, for every later one right behind the last products of its predecessor (under that item's epilogue)
+    auto load_outer = [&](int item) {
+        int b, h, o0;
+        item_coords(item, &b, &h, &o0);
+        const bf16_t* qbase = qkv + (size_t)b * N * rs + (size_t)h * DH;
+        const bf16_t* dobase = dO + (size_t)b * N * D + (size_t)h * DH;
+        const int orow = (o0 + r < N) ? o0 + r : N - 1;
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            if constexpr (MODE == MODE_DQ) {
+                f1[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + ks * 16 + hi * 8);             // Q
+                f2[ks] = *(const bf16x8*)(dobase + (size_t)orow * D + ks * 16 + hi * 8);             // dO
+            } else {
+                f1[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + D + ks * 16 + hi * 8);         // K
+                f2[ks] = *(const bf16x8*)(qbase + (size_t)orow * rs + 2 * D + ks * 16 + hi * 8);     // V
+            }
+        }
+        if constexpr (MODE == MODE_DQ) {
+            const size_t base = ((size_t)b * H + h) * N;
+            oL = lse[base + orow];
+            oD = delta[base + orow];
+        }
+    };
+    f32x16 acc1[G::DB], acc2[G::DB];  // DQ: acc1 = dQ^T.  DKV: acc1 = dK^T, acc2 = dV^T
+
+    int item = blockIdx.x, chunk = 0;
+    if (item < nitems) {
+        prefetch(item, chunk);
+        load_outer(item);
+    }
+    while (item < nitems) {
+        const int ic0 = chunk * IC, nin = chunk_rows(chunk);
+        __syncthreads();  // the previous unit's products (and an epilogue's reads of its LDS block) are done
+        // ---- commit the staged unit: registers -> the LDS images
+        {
+            const int total = nin * G::CHUNKS;
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int idx = tid + it * nthreads;
+                if (idx < total) {
+                    const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+                    *(bf16x8*)(R1 + (size_t)row * G::RS + c * 16) = pv1[it];
+                    *(bf16x8*)(R2 + (size_t)row * G::RS + c * 16) = pv2[it];
+                    *(bf16x8*)(T1 + (size_t)row * G::TS + c * 16) = pv1[it];
+                    if constexpr (MODE == MODE_DKV) *(bf16x8*)(T2 + (size_t)row * G::TS + c * 16) = pv2[it];
+                }
+            }
+            if constexpr (MODE == MODE_DKV) {
+                if (tid < nin) {
+                    rowL[tid] = pL;
+                    rowD[tid] = pD;
+                }
+            }
+            if (chunk == 0) {
+#pragma unroll
+                for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { acc1[d][e] = 0.f; acc2[d][e] = 0.f; }
             }
         }
         __syncthreads();
+        // ---- the next unit's loads go out now and land during this unit's products
+        int nitem = item, nchunk = chunk + 1;
+        if (nchunk == nchunks) {
+            nchunk = 0;
+            nitem = item + gridDim.x;
+        }
+        if (nitem < nitems) prefetch(nitem, nchunk);
 
         const int ntiles = nin >> 5;
         for (int t = 0; t < ntiles; ++t) {
@@ -201,36 +263,44 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
                 }
             }
         }
-    }
 
-    // ---- store: the accumulators hold lane = outer row, registers = d (4 consecutive per group). Written from there,
-    // one head's 128-byte row segment went out as 16 separate 8-byte pieces; the tile is turned through a wave-private
-    // LDS block instead (the operand images are dead after the barrier) and leaves as 16-byte chunks, 8 lanes per row.
-    __syncthreads();
-    unsigned char* ob = smem + (size_t)wave * 32 * G::RS;
+        if (chunk == nchunks - 1) {
+            // ---- store: the accumulators hold lane = outer row, registers = d (4 consecutive per group). Written from
+            // there, one head's 128-byte row segment went out as 16 separate 8-byte pieces; the tile is turned through a
+            // wave-private LDS block instead (the operand images are dead after the barrier) and leaves as 16-byte
+            // chunks, 8 lanes per row.
+            int b, h, o0;
+            item_coords(item, &b, &h, &o0);
+            if (nitem < nitems) load_outer(nitem);
+            __syncthreads();
+            unsigned char* ob = smem + (size_t)wave * 32 * G::RS;
 #pragma unroll
-    for (int which = 0; which < (MODE == MODE_DKV ? 2 : 1); ++which) {
+            for (int which = 0; which < (MODE == MODE_DKV ? 2 : 1); ++which) {
 #pragma unroll
-        for (int d = 0; d < G::DB; ++d)
+                for (int d = 0; d < G::DB; ++d)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = d * 32 + 8 * g4 + 4 * hi;
-                if (d0 < DH) {
-                    bf16x4 v;
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int d0 = d * 32 + 8 * g4 + 4 * hi;
+                        if (d0 < DH) {
+                            bf16x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = which == 0 ? (bf16_t)(acc1[d][g4 * 4 + e] * scale) : (bf16_t)acc2[d][g4 * 4 + e];
-                    *(bf16x4*)(ob + (size_t)r * G::RS + d0 * 2) = v;
+                            for (int e = 0; e < 4; ++e)
+                                v[e] = which == 0 ? (bf16_t)(acc1[d][g4 * 4 + e] * scale) : (bf16_t)acc2[d][g4 * 4 + e];
+                            *(bf16x4*)(ob + (size_t)r * G::RS + d0 * 2) = v;
+                        }
+                    }
+                __syncthreads();  // (the block is wave-private; the barriers only pin the order of its writes and reads)
+                bf16_t* obase = dqkv + (size_t)b * N * rs + (size_t)h * DH + (MODE == MODE_DKV ? D : 0) + (which ? D : 0);
+                for (int idx = lane; idx < 32 * G::CHUNKS; idx += 64) {
+                    const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+                    const bf16x8 v = *(const bf16x8*)(ob + (size_t)row * G::RS + c * 16);
+                    if (o0 + row < N) *(bf16x8*)(obase + (size_t)(o0 + row) * rs + c * 8) = v;  // dQ / dK (which 0), dV (which 1)
                 }
+                if (MODE == MODE_DKV && which == 0) __syncthreads();
             }
-        __syncthreads();  // (the block is wave-private; the barriers only pin the order of its writes and reads)
-        bf16_t* obase = dqkv + (size_t)b * N * rs + (size_t)h * DH + (MODE == MODE_DKV ? D : 0) + (which ? D : 0);
-        for (int idx = lane; idx < 32 * G::CHUNKS; idx += 64) {
-            const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
-            const bf16x8 v = *(const bf16x8*)(ob + (size_t)row * G::RS + c * 16);
-            if (o0 + row < N) *(bf16x8*)(obase + (size_t)(o0 + row) * rs + c * 8) = v;  // dQ / dK (which 0), dV (which 1)
         }
-        if (MODE == MODE_DKV && which == 0) __syncthreads();
+        item = nitem;
+        chunk = nchunk;
     }
 }
 
@@ -294,23 +364,34 @@ int launch_bwd_part(const void* qkv, const void* dO, const float* lse, const flo
                     int H, hipStream_t stream) {
     using G = BGeo<DH>;
     constexpr int per_row = 2 * G::RS + (MODE == MODE_DKV ? 2 : 1) * G::TS + (MODE == MODE_DKV ? 8 : 0);
-    constexpr int LDS_MAX = 64 * 1024;
+    constexpr int LDS_MAX = 96 * 1024;  // one workgroup per CU (it is persistent and prefetches): room for long chunks
     int waves, blocks;
     pick_waves_b(N, &waves, &blocks);
+    if (waves < 4) waves = 4;  // staging wants threads (waves without outer rows only load)
+    const int threads = waves * 64;
     int icmax = (LDS_MAX / per_row) / 32 * 32;
+    const int ic_regs = (G::PIT * threads / G::CHUNKS) / 32 * 32;  // what PIT staging loads per thread cover
+    if (icmax > ic_regs) icmax = ic_regs;
+    if (MODE == MODE_DKV && icmax > threads / 32 * 32) icmax = threads / 32 * 32;  // one (L2, delta) pair per thread
+    VIT_REQUIRE(icmax >= 32, "attention_bwd: no room for a 32-row chunk");
     int IC = ((N + 31) / 32) * 32;
     if (IC > icmax) IC = icmax;
     size_t lds = (size_t)IC * per_row;
     if (lds < (size_t)waves * 32 * G::RS) lds = (size_t)waves * 32 * G::RS;  // the store epilogue's per-wave blocks
     auto kern = attn_bwd_kernel<DH, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        VIT_CHECK_HIP(hipGetDevice(&dev));
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX + 8 * 1024));
-        attr_set = true;
+        VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
+    const long nitems = (long)batch * H * blocks;
+    VIT_REQUIRE(nitems < (1L << 31), "attention_bwd: too many (batch, head, block) items");
+    const int grid = nitems < ncu ? (int)nitems : ncu;
     const float scale = 1.0f / sqrtf((float)DH);
-    hipLaunchKernelGGL(kern, dim3(batch * H, blocks), dim3(waves * 64), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dO,
-                       lse, delta, (bf16_t*)dqkv, N, H, IC, scale * LOG2E, scale);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dO, lse, delta,
+                       (bf16_t*)dqkv, N, H, IC, blocks, (int)nitems, scale * LOG2E, scale);
     VIT_CHECK_HIP(hipGetLastError());
     return VIT_OK;
 }
