@@ -83,6 +83,31 @@ def test_linear(m, n, k, dtype, epi):
     assert rel_err(out, ref) < (1e-5 if dtype == torch.float32 else BF16_TOL)
 
 
+@pytest.mark.parametrize("m,n,k", [(5001, 1000, 256), (4200, 1096, 384)])
+@pytest.mark.parametrize("epi", ["none", "gelu", "quick_gelu", "residual", "nobias"])
+def test_linear_persistent_kernel_ragged_columns(m, n, k, epi):
+    # M * N >= 64 tiles and K % 128 == 0: the persistent kernel, with a ragged last tile ROW and a ragged last tile
+    # COLUMN (n % 256 = 232 / 72): its bias / folded terms travel through LDS by a DMA whose out-of-range lanes must
+    # read as zero, and the stores of columns >= n must be dropped
+    x, w = q(rnd((m, k), "rg.x")), q(rnd((n, k), "rg.w", 1 / math.sqrt(k)))
+    bias = None if epi == "nobias" else rnd((n,), "rg.b", 0.5)
+    res = q(rnd((m, n), "rg.r")) if epi == "residual" else None
+    ref = x @ w.t()
+    if bias is not None:
+        ref = ref + bias
+    if epi in ("gelu", "quick_gelu"):
+        ref = vit_oracle.activation(ref, epi)
+    if res is not None:
+        ref = ref + res
+    out = ops.linear(x.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), None if bias is None else bias.to(DEV),
+                     activation=epi if epi in ("gelu", "quick_gelu") else None,
+                     residual=None if res is None else res.to(DEV, torch.bfloat16))
+    assert tuple(out.shape) == (m, n)
+    assert rel_err(out, ref) < BF16_TOL
+    # the last rows / columns on their own (a wrong edge hides in a whole-matrix norm)
+    assert rel_err(out[-40:, -80:], ref[-40:, -80:]) < 2 * BF16_TOL
+
+
 def test_linear_identity_asymmetric():
     # A = I with an asymmetric W catches transposed / permuted output maps exactly
     n = 256
