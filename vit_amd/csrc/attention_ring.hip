@@ -13,11 +13,12 @@
 //  * counted waits as in attention_dh64.hip with two DMA instructions per tile and eight Q pieces per item.
 #include "vit_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int NW = 8;  // waves per workgroup
+constexpr int NDMA = 8;  // waves of a workgroup that issue the K / V DMA (4 rows each = one 32-key tile); a workgroup has 8..12 waves
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -62,15 +63,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, (int)lane_off, uni_off, 0, 0);
 }
 
-template <int DH, int R, bool LSE>
-__global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc src, bf16_t* __restrict__ out,
+// NWV waves per workgroup = 32-query tiles per item. The sequence's tiles are dealt out over ceil(tiles / NWV) items per
+// (batch, head), and an item costs about the same whatever the number of its waves that have queries (every wave walks
+// all key tiles in lock step), so NWV is chosen per sequence length to minimise the item count: 1025 tokens = 33 tiles
+// are 3 items of 11 waves instead of 5 items of 8 (the fifth with a single query row).
+template <int DH, int R, bool LSE, int NWV>
+__global__ __launch_bounds__(NWV * 64) void attention_ring_kernel(const RingSrc src, bf16_t* __restrict__ out,
                                                                   float* __restrict__ lse, int N, int H, int nitems,
                                                                   int qblocks, float scale_log2e) {
     using G = RingGeo<DH>;
     constexpr int ST = G::ST + (LSE ? 1 : 0);
     constexpr int NQ = G::NQ;
     constexpr int C = 2;  // DMA instructions per wave and tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // R slots, then NW Q slots
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // R slots, then NWV Q slots
 
     const unsigned smem_lds = (unsigned)(uintptr_t)LDS_PTR(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc s
     const int D = H * DH;
     const int rs2 = src.rs2;
     const int nt = (N + 31) >> 5;
+    const bool dma_wave = wave < NDMA;  // wave-uniform
 
     const int nmy = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     if (nmy <= 0) return;  // uniform
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc s
     // ---- prologue
     int qb;
     int bh = item_bh(0, &qb);
-    int q0 = (qb * NW + wave) * 32;
+    int q0 = (qb * NWV + wave) * 32;
     __amdgpu_buffer_rsrc_t pkr = item_rsrc(src.k, bh), pvr = item_rsrc(src.v, bh);  // item the DMA cursor is in
     dma_q(item_rsrc(src.q, bh), q0);
     int pj = 0, pt = 0;
@@ -152,8 +158,10 @@ __global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc s
             pvr = item_rsrc(src.v, nb);
         }
     };
+    if (dma_wave) {
 #pragma unroll
-    for (int s = 0; s < R - 1; ++s) dma_next(s);
+        for (int s = 0; s < R - 1; ++s) dma_next(s);
+    }
 
     f32x16 o[G::DB];
 #pragma unroll
@@ -174,10 +182,16 @@ __global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc s
                 const bool inwin = p <= R - 2;
                 const bool stin = inwin && prev_active;
                 const bool qin = inwin && p >= 1;
-                if (stin) {
-                    if (qin) wait_vm<(R - 2) * C + NQ + ST>(); else wait_vm<(R - 2) * C + ST>();
-                } else {
-                    if (qin) wait_vm<(R - 2) * C + NQ>(); else wait_vm<(R - 2) * C>();
+                if (dma_wave) {
+                    if (stin) {
+                        if (qin) wait_vm<(R - 2) * C + NQ + ST>(); else wait_vm<(R - 2) * C + ST>();
+                    } else {
+                        if (qin) wait_vm<(R - 2) * C + NQ>(); else wait_vm<(R - 2) * C>();
+                    }
+                } else if (p == 0) {
+                    // a wave without tile DMAs only has its Q prefetch to wait for (issued at p = 0 of the previous item,
+                    // older than that item's stores): before its Q fragments are read, everything but the stores is in
+                    if (prev_active) wait_vm<ST>(); else wait_vm<0>();
                 }
             }
             asm volatile("s_barrier" ::: "memory");
@@ -190,9 +204,9 @@ __global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc s
                 const int jn = j + 1 < nmy ? j + 1 : j;
                 int nqb;
                 const int nbh = item_bh(jn, &nqb);
-                dma_q(item_rsrc(src.q, nbh), (nqb * NW + wave) * 32);
+                dma_q(item_rsrc(src.q, nbh), (nqb * NWV + wave) * 32);
             }
-            dma_next(pslot);
+            if (dma_wave) dma_next(pslot);
             pslot = pslot + 1 == R ? 0 : pslot + 1;
 
             if (active) {
@@ -320,17 +334,17 @@ __global__ __launch_bounds__(NW * 64) void attention_ring_kernel(const RingSrc s
         prev_active = active;
         if (j + 1 < nmy) {
             bh = item_bh(j + 1, &qb);
-            q0 = (qb * NW + wave) * 32;
+            q0 = (qb * NWV + wave) * 32;
         }
     }
     wait_vm<0>();  // the dummy DMAs of the tail must land before the LDS is released
 }
 
-template <int DH, int R>
+template <int DH, int R, int NWV>
 int launch_ring(const void* qkv, void* out, float* lse, int batch, int N, int H, hipStream_t stream) {
     using G = RingGeo<DH>;
-    constexpr int LDS = R * G::SLOT + NW * G::QSLOT;
-    const int qblocks = ceil_div(ceil_div(N, 32), NW);
+    constexpr int LDS = R * G::SLOT + NWV * G::QSLOT;
+    const int qblocks = ceil_div(ceil_div(N, 32), NWV);
     const long nitems = (long)batch * H * qblocks;
     VIT_REQUIRE(nitems < (1L << 31), "attention: too many (batch, head, query block) items");
     VIT_REQUIRE((long)N * 3 * H * DH * 2 < (1L << 31), "attention: one image's qkv rows exceed 2 GiB");
@@ -339,9 +353,9 @@ int launch_ring(const void* qkv, void* out, float* lse, int batch, int N, int H,
         int dev, cus, per_cu = 0;
         VIT_CHECK_HIP(hipGetDevice(&dev));
         VIT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)attention_ring_kernel<DH, R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)attention_ring_kernel<DH, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        VIT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)attention_ring_kernel<DH, R, false>, NW * 64, LDS));
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)attention_ring_kernel<DH, R, false, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)attention_ring_kernel<DH, R, true, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        VIT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)attention_ring_kernel<DH, R, false, NWV>, NWV * 64, LDS));
         resident = cus * (per_cu > 0 ? per_cu : 1);
     }
     const int grid = nitems < resident ? (int)nitems : resident;
@@ -350,11 +364,11 @@ int launch_ring(const void* qkv, void* out, float* lse, int batch, int N, int H,
     const unsigned char* p = (const unsigned char*)qkv;
     RingSrc src{p, p + (size_t)D * 2, p + (size_t)2 * D * 2, (long)N * 3 * D * 2, (long)DH * 2, 3 * D * 2};
     if (lse)
-        hipLaunchKernelGGL((attention_ring_kernel<DH, R, true>), dim3(grid), dim3(NW * 64), LDS, stream, src, (bf16_t*)out, lse, N, H,
-                           (int)nitems, qblocks, scale_log2e);
+        hipLaunchKernelGGL((attention_ring_kernel<DH, R, true, NWV>), dim3(grid), dim3(NWV * 64), LDS, stream, src, (bf16_t*)out, lse, N,
+                           H, (int)nitems, qblocks, scale_log2e);
     else
-        hipLaunchKernelGGL((attention_ring_kernel<DH, R, false>), dim3(grid), dim3(NW * 64), LDS, stream, src, (bf16_t*)out, lse, N, H,
-                           (int)nitems, qblocks, scale_log2e);
+        hipLaunchKernelGGL((attention_ring_kernel<DH, R, false, NWV>), dim3(grid), dim3(NWV * 64), LDS, stream, src, (bf16_t*)out, lse, N,
+                           H, (int)nitems, qblocks, scale_log2e);
     VIT_CHECK_HIP(hipGetLastError());
     return VIT_OK;
 }
@@ -376,5 +390,21 @@ bool attention_ring_eligible(int N, int head_dim) {
 
 int launch_attention_ring(const void* qkv, void* out, float* lse, int batch, int N, int H, int head_dim, hipStream_t stream) {
     VIT_REQUIRE(attention_ring_eligible(N, head_dim), "attention ring: head_dim %d / N %d not eligible", head_dim, N);
-    return launch_ring<80, kRing80>(qkv, out, lse, batch, N, H, stream);
+    // Waves per workgroup: items per (batch, head) x the relative cost of an item, measured at 1025 tokens, batch 32
+    // (8 waves = two per SIMD: 69; 9..12 = three on at least one SIMD: 87..100). 33 tiles -> 12 waves (3 items, 299 us
+    // against 345 us with 5 items of 8), 9 tiles -> 9, 16 tiles -> 8. VIT_AMD_RING_WAVES forces a count (lab).
+    static const int forced = getenv("VIT_AMD_RING_WAVES") ? atoi(getenv("VIT_AMD_RING_WAVES")) : 0;
+    static const int item_cost[13] = {0, 0, 0, 0, 0, 0, 0, 0, 69, 87, 92, 100, 100};
+    const int tiles = ceil_div(N, 32);
+    int nwv = 8;
+    for (int w = 9; w <= 12; ++w)
+        if (ceil_div(tiles, w) * item_cost[w] <= ceil_div(tiles, nwv) * item_cost[nwv]) nwv = w;
+    if (forced >= 8 && forced <= 12) nwv = forced;
+    switch (nwv) {
+        case 9: return launch_ring<80, kRing80, 9>(qkv, out, lse, batch, N, H, stream);
+        case 10: return launch_ring<80, kRing80, 10>(qkv, out, lse, batch, N, H, stream);
+        case 11: return launch_ring<80, kRing80, 11>(qkv, out, lse, batch, N, H, stream);
+        case 12: return launch_ring<80, kRing80, 12>(qkv, out, lse, batch, N, H, stream);
+    }
+    return launch_ring<80, kRing80, 8>(qkv, out, lse, batch, N, H, stream);
 }
