@@ -110,6 +110,10 @@ def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
             ach = nbytes / dt
             out[name] = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": ach / HBM_PEAK, "us_per_launch": dt * 1e6, "launches_per_forward": per_fwd}
+    if 64 % cfg.patch_size:
+        # the stand-alone operator has no workspace and gathers per element; vit_forward first gathers the patch rows
+        # into its workspace (im2col_rows_kernel) and runs the persistent GEMM on them (profiles/: ~0.2 ms in all)
+        out["patch_embed"]["note"] = "stand-alone vit_patch_embed_fwd (gather loader); vit_forward uses im2col_rows + the persistent GEMM"
     return out
 
 
