@@ -148,6 +148,9 @@ ATTN_CASES = [  # batch, seq, heads, head_dim
     # resident workgroups (37*16 = 592 items > 512) and fewer items than workgroups
     (2, 96, 2, 64), (2, 97, 2, 64), (3, 128, 2, 64), (2, 129, 3, 64), (2, 256, 2, 64), (2, 257, 2, 64),
     (37, 197, 16, 64), (1, 1025, 3, 64), (5, 161, 7, 64),
+    # head_dim 80 ring kernel, one case per workgroup size its policy picks (tiles = ceil(n / 32)):
+    # 7 tiles -> 8 waves, 9 -> 9, 10 -> 10, 11 -> 11, 16 -> 8 (two full items), 21 -> 11 (two items), 33 -> 12
+    (3, 193, 2, 80), (2, 257, 3, 80), (2, 320, 2, 80), (2, 340, 2, 80), (1, 512, 2, 80), (1, 660, 2, 80), (2, 1025, 2, 80),
 ]
 
 
