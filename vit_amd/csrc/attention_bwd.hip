@@ -60,7 +60,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int row0, in
 }
 
 template <int DH, int MODE>
-__global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((MODE == MODE_DQ && DH <= 64) ? 4 : 2))) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                        const float* __restrict__ lse, const float* __restrict__ delta,
                                                        bf16_t* __restrict__ dqkv, int N, int H, int IC, int blocks, int nitems,
                                                        float scale_log2e, float scale) {
@@ -85,8 +85,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     const int tr_key = 4 * (g >> 1) + (i16 >> 2);
     const int tr_col = ((g & 1) * 16 + 4 * (i16 & 3)) * 2;
 
-    // ---- staging registers of the NEXT unit
-    constexpr int PIT = G::PIT;
+    // ---- staging registers of the NEXT unit. Only the dK/dV launch prefetches: its 157 VGPRs allow one workgroup per
+    // CU anyway, so nothing else hides its loads. The dQ launch fits 124 VGPRs = two workgroups per CU, which overlap
+    // each other's staging; the prefetch registers would cost it the second workgroup (122 -> 138 us, measured).
+    constexpr bool PF = (MODE == MODE_DKV);
+    constexpr int PIT = PF ? G::PIT : 1;
     bf16x8 pv1[PIT], pv2[PIT];
     float pL = 0.f, pD = 0.f;                    // DKV: L2 / delta of inner row tid of the chunk
     auto item_coords = [&](int item, int* b, int* h, int* o0) {
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
         return (nin > IC) ? IC : ((nin + 31) & ~31);
     };
     auto prefetch = [&](int item, int chunk) {
+        if constexpr (!PF) return;
         int b, h, o0;
         item_coords(item, &b, &h, &o0);
         const bf16_t* qbase = qkv + (size_t)b * N * rs + (size_t)h * DH;          // q | k (+D) | v (+2D)
@@ -168,18 +172,35 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     while (item < nitems) {
         const int ic0 = chunk * IC, nin = chunk_rows(chunk);
         __syncthreads();  // the previous unit's products (and an epilogue's reads of its LDS block) are done
-        // ---- commit the staged unit: registers -> the LDS images
+        // ---- commit the staged unit: registers -> the LDS images (dQ launch: global -> LDS here)
         {
             const int total = nin * G::CHUNKS;
+            if constexpr (PF) {
 #pragma unroll
-            for (int it = 0; it < PIT; ++it) {
-                const int idx = tid + it * nthreads;
-                if (idx < total) {
+                for (int it = 0; it < PIT; ++it) {
+                    const int idx = tid + it * nthreads;
+                    if (idx < total) {
+                        const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+                        *(bf16x8*)(R1 + (size_t)row * G::RS + c * 16) = pv1[it];
+                        *(bf16x8*)(R2 + (size_t)row * G::RS + c * 16) = pv2[it];
+                        *(bf16x8*)(T1 + (size_t)row * G::TS + c * 16) = pv1[it];
+                        if constexpr (MODE == MODE_DKV) *(bf16x8*)(T2 + (size_t)row * G::TS + c * 16) = pv2[it];
+                    }
+                }
+            } else {
+                int b, h, o0;
+                item_coords(item, &b, &h, &o0);
+                const bf16_t* qbase = qkv + (size_t)b * N * rs + (size_t)h * DH;
+                for (int idx = tid; idx < total; idx += nthreads) {
                     const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
-                    *(bf16x8*)(R1 + (size_t)row * G::RS + c * 16) = pv1[it];
-                    *(bf16x8*)(R2 + (size_t)row * G::RS + c * 16) = pv2[it];
-                    *(bf16x8*)(T1 + (size_t)row * G::TS + c * 16) = pv1[it];
-                    if constexpr (MODE == MODE_DKV) *(bf16x8*)(T2 + (size_t)row * G::TS + c * 16) = pv2[it];
+                    int gr = ic0 + row;
+                    if (gr > N - 1) gr = N - 1;  // pad rows re-read the last row; they are masked below
+                    const bf16_t* p = qbase + (size_t)gr * rs + c * 8;
+                    const bf16x8 v1 = *(const bf16x8*)(p + D);       // K
+                    const bf16x8 v2 = *(const bf16x8*)(p + 2 * D);   // V
+                    *(bf16x8*)(R1 + (size_t)row * G::RS + c * 16) = v1;
+                    *(bf16x8*)(R2 + (size_t)row * G::RS + c * 16) = v2;
+                    *(bf16x8*)(T1 + (size_t)row * G::TS + c * 16) = v1;
                 }
             }
             if constexpr (MODE == MODE_DKV) {
@@ -364,18 +385,21 @@ int launch_bwd_part(const void* qkv, const void* dO, const float* lse, const flo
                     int H, hipStream_t stream) {
     using G = BGeo<DH>;
     constexpr int per_row = 2 * G::RS + (MODE == MODE_DKV ? 2 : 1) * G::TS + (MODE == MODE_DKV ? 8 : 0);
-    constexpr int LDS_MAX = 96 * 1024;  // one workgroup per CU (it is persistent and prefetches): room for long chunks
+    // dK/dV: one workgroup per CU (it prefetches): room for long chunks. dQ: two per CU.
+    constexpr int LDS_MAX = (MODE == MODE_DKV ? 96 : 64) * 1024;
     int waves, blocks;
     pick_waves_b(N, &waves, &blocks);
     if (waves < 4) waves = 4;  // staging wants threads (waves without outer rows only load)
     const int threads = waves * 64;
     int icmax = (LDS_MAX / per_row) / 32 * 32;
     const int ic_regs = (G::PIT * threads / G::CHUNKS) / 32 * 32;  // what PIT staging loads per thread cover
-    if (icmax > ic_regs) icmax = ic_regs;
+    if (MODE == MODE_DKV && icmax > ic_regs) icmax = ic_regs;
     if (MODE == MODE_DKV && icmax > threads / 32 * 32) icmax = threads / 32 * 32;  // one (L2, delta) pair per thread
     VIT_REQUIRE(icmax >= 32, "attention_bwd: no room for a 32-row chunk");
-    int IC = ((N + 31) / 32) * 32;
-    if (IC > icmax) IC = icmax;
+    // chunks of equal length (197 rows: 112 + 112 rather than 192 + 32: every chunk costs two barriers and a staging pass)
+    const int npad = ((N + 31) / 32) * 32;
+    const int nchunks = ceil_div(npad, icmax);
+    const int IC = ((ceil_div(npad, nchunks) + 31) / 32) * 32;
     size_t lds = (size_t)IC * per_row;
     if (lds < (size_t)waves * 32 * G::RS) lds = (size_t)waves * 32 * G::RS;  // the store epilogue's per-wave blocks
     auto kern = attn_bwd_kernel<DH, MODE>;
@@ -386,9 +410,13 @@ int launch_bwd_part(const void* qkv, const void* dO, const float* lse, const flo
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX + 8 * 1024));
         VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     }
+    int per_cu = 1;
+    VIT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, threads, lds));
+    if (per_cu < 1) per_cu = 1;
     const long nitems = (long)batch * H * blocks;
     VIT_REQUIRE(nitems < (1L << 31), "attention_bwd: too many (batch, head, block) items");
-    const int grid = nitems < ncu ? (int)nitems : ncu;
+    const long resident = (long)ncu * per_cu;
+    const int grid = nitems < resident ? (int)nitems : (int)resident;
     const float scale = 1.0f / sqrtf((float)DH);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dO, lse, delta,
                        (bf16_t*)dqkv, N, H, IC, blocks, (int)nitems, scale * LOG2E, scale);
