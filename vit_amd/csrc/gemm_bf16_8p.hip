@@ -539,7 +539,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pv), Pr, (int)voff, 0, G8_STORE_AUX);
                         }
                         if constexpr (EPI == VIT_EPI_GELU) {
-                            const f32x2 g0 = act_gelu_pk(f32x2{v[0], v[1]}), g1 = act_gelu_pk(f32x2{v[2], v[3]});
+                            f32x2 g0 = f32x2{v[0], v[1]}, g1 = f32x2{v[2], v[3]};
+                            act_gelu_pk2(g0, g1);
                             v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
                         }
                         if constexpr (EPI == VIT_EPI_QUICK_GELU) {
@@ -548,10 +549,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                         }
                         if constexpr (USES_RES) {
                             const bf16x4 r = __builtin_bit_cast(bf16x4, rres[ha * 16 + mi * 4 + j]);
+                            if constexpr (EPI == VIT_EPI_DGELU) {
+                                const f32x2 g0 = act_dgelu_pk(f32x2{(float)r[0], (float)r[1]}), g1 = act_dgelu_pk(f32x2{(float)r[2], (float)r[3]});
+                                v[0] *= g0.x; v[1] *= g0.y; v[2] *= g1.x; v[3] *= g1.y;
+                            } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if constexpr (EPI == VIT_EPI_RESIDUAL) v[e] += (float)r[e];
-                                else v[e] *= act_grad<EPI>((float)r[e]);
+                                for (int e = 0; e < 4; ++e) {
+                                    if constexpr (EPI == VIT_EPI_RESIDUAL) v[e] += (float)r[e];
+                                    else v[e] *= act_grad<EPI>((float)r[e]);
+                                }
                             }
                         }
                         if constexpr (OUTM == 1) {

@@ -40,52 +40,70 @@ __device__ __forceinline__ float act_quick_gelu(float x) {
 }
 
 // GELU of the bf16 kernels, on two elements at once: in the persistent GEMM's epilogue the activation is the
-// exposed cost (128 elements per lane and tile): no transcendental, and the multiplies / FMAs
-// are written on float2 so they become v_pk_mul_f32 / v_pk_fma_f32 (2 elements per issue).
-//   erf(z) = z h(z^2) with h a degree-8 minimax-style fit on z^2 in [0, 9] (Chebyshev-node least
-//   squares), z^2 clamped to 9 and the product clamped to [-1, 1], so both tails are exact.
-// |gelu error| <= 7.7e-5 over all x (largest near |x| = 4, where one bf16 ulp of the result is
+// exposed cost (128 elements per lane and tile): no transcendental, every operation packed (2 elements per issue).
+//   gelu(x) = x Phi(x),  Phi(x) = 1/2 + x q(x^2),  x q(x^2) = erf(x / sqrt2) / 2
+// with q a degree-8 minimax-style fit (Chebyshev-node least squares of erf(z) = z h(z^2) on z^2 in [0, 9], rescaled
+// to x^2). Phi is clamped to [0, 1] by the CLAMP bit of the packed fma itself: beyond the fitted interval the
+// polynomial keeps |x q| >= 1/2 + 7e-6 (checked to |x| = 56; its leading coefficient is positive), so both tails are
+// exact without clamping x^2. 11 packed instructions per pair (the form with z = x / sqrt2, min(z^2, 9), med3 and
+// x/2 (1 + erf) took 13 packed + 4 single ones).
+// |gelu error| <= 8.5e-5 over all x (largest near |x| = 4.2, where one bf16 ulp of the result is
 // 1.6e-2; <= 2e-5 for |x| <= 2), i.e. below the bf16 rounding of the stored activation.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, float c) { return __builtin_elementwise_fma(a, b, f32x2{c, c}); }
-__device__ __forceinline__ f32x2 act_gelu_pk(f32x2 x) {
+// Phi(x) = clamp(1/2 + x q(x^2), 0, 1) on two elements
+__device__ __forceinline__ f32x2 act_phi_pk(f32x2 x, f32x2 u) {
     // every multiply-add is an explicit fma: the same bits from every kernel that inlines this,
     // whatever the compiler would have contracted
-    const f32x2 z = x * 0.70710678118654752440f;
-    f32x2 u = z * z;
-    u.x = fminf(u.x, 9.0f);
-    u.y = fminf(u.y, 9.0f);
-    f32x2 p = pk_fma(u, f32x2{4.9182759198629356e-08f, 4.9182759198629356e-08f}, -2.2677306787954876e-06f);
-    p = pk_fma(p, u, 4.6147291868692264e-05f);
-    p = pk_fma(p, u, -0.0005535572418011725f);
-    p = pk_fma(p, u, 0.004437862429767847f);
-    p = pk_fma(p, u, -0.02564961276948452f);
-    p = pk_fma(p, u, 0.11186250299215317f);
-    p = pk_fma(p, u, -0.3758186101913452f);
-    p = pk_fma(p, u, 1.1283628940582275f);
-    f32x2 s = z * p;
-    s.x = __builtin_amdgcn_fmed3f(s.x, -1.0f, 1.0f);
-    s.y = __builtin_amdgcn_fmed3f(s.y, -1.0f, 1.0f);
-    const f32x2 t = x * 0.5f;
-    return __builtin_elementwise_fma(t, s, t);
+    f32x2 p = pk_fma(u, f32x2{6.79247283419393e-11f, 6.79247283419393e-11f}, -6.263780161219756e-09f);
+    p = pk_fma(p, u, 2.549301711951557e-07f);
+    p = pk_fma(p, u, -6.116001259215409e-06f);
+    p = pk_fma(p, u, 9.806382877286524e-05f);
+    p = pk_fma(p, u, -0.0011335634626448154f);
+    p = pk_fma(p, u, 0.009887341409921646f);
+    p = pk_fma(p, u, -0.06643597036600113f);
+    p = pk_fma(p, u, 0.39893653988838196f);
+    f32x2 phi;  // clamp(x p + 1/2, 0, 1): the compiler spends two v_max ... clamp on this, the instruction has the bit
+    asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(phi) : "v"(x), "v"(p));
+    return phi;
+}
+__device__ __forceinline__ f32x2 act_gelu_pk(f32x2 x) { return x * act_phi_pk(x, x * x); }
+// two pairs at once, the two Horner chains interleaved: a packed fma that reads the previous one's result needs a wait
+// state (the compiler fills it with s_nop when it has only one chain to schedule). Same bits as act_gelu_pk.
+__device__ __forceinline__ void act_gelu_pk2(f32x2& xa, f32x2& xb) {
+    const f32x2 ua = xa * xa, ub = xb * xb;
+    f32x2 pa = pk_fma(ua, f32x2{6.79247283419393e-11f, 6.79247283419393e-11f}, -6.263780161219756e-09f);
+    f32x2 pb = pk_fma(ub, f32x2{6.79247283419393e-11f, 6.79247283419393e-11f}, -6.263780161219756e-09f);
+#define VIT_GELU_STEP(C) pa = pk_fma(pa, ua, C); pb = pk_fma(pb, ub, C)
+    VIT_GELU_STEP(2.549301711951557e-07f);
+    VIT_GELU_STEP(-6.116001259215409e-06f);
+    VIT_GELU_STEP(9.806382877286524e-05f);
+    VIT_GELU_STEP(-0.0011335634626448154f);
+    VIT_GELU_STEP(0.009887341409921646f);
+    VIT_GELU_STEP(-0.06643597036600113f);
+    VIT_GELU_STEP(0.39893653988838196f);
+#undef VIT_GELU_STEP
+    f32x2 fa, fb;
+    asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(fa) : "v"(xa), "v"(pa));
+    asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(fb) : "v"(xb), "v"(pb));
+    xa = xa * fa;
+    xb = xb * fb;
 }
 // the same function on one element (generic GEMM kernel): identical bits to act_gelu_pk
 __device__ __forceinline__ float act_gelu_poly(float x) { return act_gelu_pk(f32x2{x, x}).x; }
 
-// gelu'(x) = Phi(x) + x phi(x), Phi(-|x|) = erfc(|x|/sqrt2)/2 from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7;
-// backward of ViTMLP's activation)
-__device__ __forceinline__ float act_dgelu_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
-    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
-    p = fmaf(p, t, 0.5f * 1.421413741f);
-    p = fmaf(p, t, 0.5f * -0.284496736f);
-    p = fmaf(p, t, 0.5f * 0.254829592f);
-    p = p * t * e;                                  // 0.5 erfc(|x|/sqrt2) = Phi(-|x|)
-    const float cdf = x > 0.f ? 1.0f - p : p;
-    return fmaf(x * e, 0.3989422804014327f, cdf);
+// gelu'(x) = Phi(x) + x phi(x) (backward of ViTMLP's activation): Phi from the packed polynomial above (|error| <= 2e-5),
+// phi(x) = exp2(-x^2 log2(e) / 2) / sqrt(2 pi). 13 packed instructions + 2 exponentials per pair; the form it replaces
+// (Abramowitz-Stegun 7.1.26 erfc with a reciprocal and an exponential per element, ~25 issue slots each) made the
+// fc2 data-gradient GEMM's epilogue a quarter of its launch.
+__device__ __forceinline__ f32x2 act_dgelu_pk(f32x2 x) {
+    const f32x2 u = x * x;
+    const f32x2 phi = act_phi_pk(x, u);
+    const f32x2 a = u * (-0.5f * 1.4426950408889634f);
+    const f32x2 xe = x * f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    return __builtin_elementwise_fma(xe, f32x2{0.3989422804014327f, 0.3989422804014327f}, phi);
 }
+__device__ __forceinline__ float act_dgelu_as(float x) { return act_dgelu_pk(f32x2{x, x}).x; }
 __device__ __forceinline__ float act_dquick_gelu(float x) {
     const float sg = 1.0f / (1.0f + __expf(-1.702f * x));
     return sg * (1.0f + 1.702f * x * (1.0f - sg));
