@@ -9,7 +9,8 @@
 //  * tile 256 (m) x 256 (n), 8 waves (2 x 4), wave tile 128 x 64, one workgroup per CU, an LDS ring of
 //    four slots of [32 tokens][256 features] per operand, fed by buffer-resource LDS-DMA three slots
 //    ahead (rows past T are outside the resource and read as zero: no padded copies), one counted
-//    vmcnt wait and one barrier per slot.
+//    vmcnt wait per slot; a slot is a read section and an MFMA section with a barrier after each, the two
+//    wave rows one barrier apart (one wave's products cover the other's LDS reads on every SIMD).
 //  * MFMA fragments (16 features x 32 tokens, 8 consecutive tokens per lane) come out of the
 //    token-major tile through ds_read_b64_tr_b16: a 16-lane group loads 4 token rows x 16 features
 //    and each lane receives one feature's 4 tokens. 8 token rows x 32 bytes are read per LDS cycle,
@@ -25,7 +26,8 @@ namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int SLOT_BYTES = 32768;            // 32 tokens x 256 features of A (16 KB) then of B (16 KB)
-constexpr int LDS_BYTES = 4 * SLOT_BYTES;    // ring of four slots
+constexpr int NSLOT = 4;                     // ring depth (the DMA runs NSLOT - 1 slots ahead; 5 slots = all 160 KiB measured the same)
+constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;
 
 struct TnParams {
     const bf16_t* A;   // dY [T, Mo]
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
     }
     const int ns = P.tok_per_split / 32;
     auto stage_slot = [&](int s) {  // slots past the split's end are fetched out of range (zeros, no traffic): vmcnt stays uniform
-        unsigned char* d = smem + (s & 3) * SLOT_BYTES + wave * 2048;
+        unsigned char* d = smem + (s & (NSLOT - 1)) * SLOT_BYTES + wave * 2048;
         const int tok = t_begin + s * 32;
         const unsigned kill = s < ns ? 0u : 0x80000000u;
 #pragma unroll
@@ -128,61 +130,56 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const TnParams P) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
-    // one k-step: the 32 tokens of the slot at LDS byte offset bo
-    auto kstep = [&](const unsigned bo) {
-            short4v bl[4], bh[4], al[8], ah[8];
-            // B fragments and the first four A fragments, then the other four A under the first MFMAs
+    // One slot = a READ section (the 24 transposed fragment reads of the slot, the DMA of the slot three ahead, the
+    // counted wait that retires this wave's pieces of the NEXT slot, lgkmcnt(0)), a barrier, an MFMA section (32 + bias
+    // products), a barrier. The two wave rows (teams wm = 0 / 1, one wave of each per SIMD) run one barrier apart, so on
+    // every SIMD one wave's products cover the other's LDS latency. Hazards, in barrier intervals (team 0 reads slot s in
+    // interval 2s, team 1 in 2s + 1): slot s + 1 is read from interval 2s + 2 on and every wave has waited for its pieces
+    // by the end of interval 2s + 1; slot s + 3 overwrites the buffer of slot s - 1 from interval 2s on, whose last reads
+    // (team 1, interval 2s - 1) were waited for (lgkmcnt(0)) before that interval's closing barrier.
+    short4v bl[4], bh[4], al[8], ah[8];
+    auto read_slot = [&](const unsigned bo) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                TR2(bl[ni], bh[ni], b_off[ni] + bo, 0);
-            }
+        for (int ni = 0; ni < 4; ++ni) {
+            TR2(bl[ni], bh[ni], b_off[ni] + bo, 0);
+        }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                TR2(al[mi], ah[mi], a_off[mi] + bo, 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]),
-                           "+v"(bh[3]), "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]),
-                           "+v"(al[3]), "+v"(ah[3])::"memory");
+        for (int mi = 0; mi < 8; ++mi) {
+            TR2(al[mi], ah[mi], a_off[mi] + bo, 0);
+        }
+    };
+    auto mma_slot = [&]() {
+        bf16x8 bfr[4];
 #pragma unroll
-            for (int mi = 4; mi < 8; ++mi) {
-                TR2(al[mi], ah[mi], a_off[mi] + bo, 0);
-            }
-            bf16x8 bfr[4];
+        for (int ni = 0; ni < 4; ++ni)
+            bfr[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(bl[ni], bh[ni], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const bf16x8 afr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[mi], ah[mi], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                bfr[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(bl[ni], bh[ni], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const bf16x8 afr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[mi], ah[mi], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
-                if (bmask & (1u << mi)) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(al[4]), "+v"(ah[4]), "+v"(al[5]), "+v"(ah[5]), "+v"(al[6]), "+v"(ah[6]), "+v"(al[7]),
-                           "+v"(ah[7])::"memory");
-#pragma unroll
-            for (int mi = 4; mi < 8; ++mi) {
-                const bf16x8 afr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[mi], ah[mi], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
-                if (bmask & (1u << mi)) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
-            }
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
+            if (bmask & (1u << mi)) bacc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, afr, bacc[mi], 0, 0, 0);
+        }
     };
-    // Prefetch distance of three slots: before slot s is read, this wave's DMAs of slots s+1 and s+2 (8 instructions)
-    // may still be in flight (two 64-token buffers with vmcnt(0) per tile were 2.7 % slower; reading slot s+1's first
-    // fragments under slot s's last MFMAs, which shortens the DMA distance to two slots, was 0.7 % slower again).
-    stage_slot(0);
-    stage_slot(1);
-    stage_slot(2);
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s) stage_slot(s);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NSLOT - 2)) : "memory");  // slot 0 landed everywhere
+    if (wm == 1) asm volatile("s_barrier" ::: "memory");            // team 1 runs one barrier behind team 0
     for (int s = 0; s < ns; ++s) {
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // slot s landed everywhere; slot s-1 is free
-        stage_slot(s + 3);
-        kstep((unsigned)((s & 3) * SLOT_BYTES));
+        read_slot((unsigned)((s & (NSLOT - 1)) * SLOT_BYTES));
+        stage_slot(s + NSLOT - 1);
+        asm volatile("s_waitcnt vmcnt(%8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]), "+v"(bl[2]), "+v"(bh[2]), "+v"(bl[3]), "+v"(bh[3])
+                     : "n"(4 * (NSLOT - 2)) : "memory");
+        asm volatile("" : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]));
+        asm volatile("" : "+v"(al[4]), "+v"(ah[4]), "+v"(al[5]), "+v"(ah[5]), "+v"(al[6]), "+v"(ah[6]), "+v"(al[7]), "+v"(ah[7]));
+        __builtin_amdgcn_sched_barrier(0);
+        mma_slot();  // (s_setprio around the products, the DMA issued before the reads: both within noise)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
     }
+    if (wm == 0) asm volatile("s_barrier" ::: "memory");  // balance team 1's extra barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the out-of-range tail DMAs still target this LDS
 
     // ---- epilogue: D = (X^T-fragment rows n) x (dY^T-fragment cols m): lane holds m = lane & 15 and the
