@@ -217,6 +217,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((MODE == MO
             }
         }
         __syncthreads();
+        // The outer fragments (global loads issued under the previous item's epilogue, or before the loop) are forced
+        // complete HERE, before the prefetch goes out. Left to the compiler the wait sits at their first use inside the
+        // tile loop, and because its bookkeeping must also cover the path on which no prefetch was issued (last unit,
+        // lanes past the chunk) it is a vmcnt(7) .. vmcnt(0) ladder there: vmcnt counts in order, so that ladder also
+        // waited for the YOUNGER prefetch loads during the first tile of every chunk.
+        if constexpr (PF) {
+#pragma unroll
+            for (int ks = 0; ks < G::KSTEPS; ++ks) asm volatile("" : "+v"(f1[ks]), "+v"(f2[ks]));
+        }
         // ---- the next unit's loads go out now and land during this unit's products
         int nitem = item, nchunk = chunk + 1;
         if (nchunk == nchunks) {
@@ -225,7 +234,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((MODE == MO
         }
         if (nitem < nitems) prefetch(nitem, nchunk);
 
+#ifdef ATTNB_LAB_SKIP  // lab only: timing without the products (results garbage)
+        const int ntiles = (nin >> 5) * (lane == 999);
+#else
         const int ntiles = nin >> 5;
+#endif
         for (int t = 0; t < ntiles; ++t) {
             // ---- S tile and dP tile: rows = 32 inner rows (registers), col = outer row (lane)
             f32x16 s, dp;
@@ -233,6 +246,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((MODE == MO
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
             const unsigned char* p1 = R1 + (size_t)(t * 32 + r) * G::RS + hi * 16;
             const unsigned char* p2 = R2 + (size_t)(t * 32 + r) * G::RS + hi * 16;
+            // (Reading all row fragments in one batch and issuing the transposed fragments of the accumulation before the
+            // P / dS arithmetic was measured for the dK/dV launch: within noise with one k-step of fragments ahead, slower
+            // with both (10 spills at 256 VGPRs). With the products removed the launch still takes 58 % of its time: it is
+            // bound by the staging round trips and the store epilogue, not by the LDS latency inside a tile.)
 #pragma unroll
             for (int ks = 0; ks < G::KSTEPS; ++ks) {
                 const bf16x8 a1 = *(const bf16x8*)(p1 + ks * 32);
@@ -243,10 +260,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((MODE == MO
             // ---- P and dS in place (register e is inner row (e&3) + 8(e>>2) + 4hi of the tile)
             if constexpr (MODE == MODE_DQ) {
                 const int key0 = ic0 + t * 32;
+                if (key0 + 32 > N) {  // wave-uniform: only the sequence's last tile has keys to mask (P = exp2(-inf) = 0)
+                    int lim = N - key0 - 4 * hi;
+                    asm volatile("" : "+v"(lim));  // (opaque: the 16 lane masks would be hoisted into 32 SGPRs)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if ((e & 3) + 8 * (e >> 2) >= lim) s[e] = -INFINITY;
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    const float p = (key < N) ? __builtin_amdgcn_exp2f(s[e] * scale_log2e - oL) : 0.f;
+                    const float p = __builtin_amdgcn_exp2f(s[e] * scale_log2e - oL);
                     s[e] = p * (dp[e] - oD);  // dS^T
                 }
             } else {
