@@ -5,6 +5,8 @@ small script in a child process (the child is started BEFORE it touches the GPU;
   and when -- the output must be bit-identical to the plain mt-major order, for every epilogue that kernel has.
 * VIT_AMD_ATTN_RING: head_dim-80 attention on the LDS-DMA ring kernel against the staged kernel it replaces (both
   fp32 online softmax over 32-key tiles; checked to bf16 tolerance, and both against the oracle in test_gpu_kernels).
+* VIT_AMD_SPLIT_PCT / VIT_AMD_STREAMS: where vit_forward cuts the batch for its two streams changes which launch a row
+  belongs to, never its arithmetic: the encoder output must be bit-identical for every cut and for a single stream.
 """
 import hashlib
 import json
@@ -48,6 +50,23 @@ print(json.dumps({"ok": bool(torch.isfinite(o).all())}))
 """
 
 
+SPLIT_SCRIPT = r"""
+import hashlib, json, torch
+from vit_amd import synth
+from vit_amd.config import ViTConfig
+from vit_amd.encoder import ViTEncoder
+dev = torch.device("cuda:0")
+cfg = ViTConfig.vit_b16_224()
+enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=dev)
+enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0, device=dev))
+px = synth.synthetic_images(cfg, 72, seed=3, device=dev).to(torch.bfloat16)   # 72 images: two chunks of >= 32 images
+out = enc(px)
+torch.cuda.synchronize()
+h = lambda t: hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
+print(json.dumps({"hidden": h(out.last_hidden_state), "pooled": h(out.pooler_output)}))
+"""
+
+
 def run_child(script, env_extra, *args):
     env = dict(os.environ)
     env.update(env_extra)
@@ -75,3 +94,9 @@ def test_ring_attention_matches_staged_kernel(tmp_path):
     assert ring.shape == staged.shape == (2, 257, 320)
     scale = staged.abs().max().item()
     assert (ring - staged).abs().max().item() <= scale / 128  # 2 bf16 ulps of the output scale
+
+
+def test_stream_split_point_does_not_change_the_bits():
+    ref = run_child(SPLIT_SCRIPT, {"VIT_AMD_STREAMS": "1"})
+    for env in ({}, {"VIT_AMD_SPLIT_PCT": "50"}, {"VIT_AMD_SPLIT_PCT": "45"}):
+        assert run_child(SPLIT_SCRIPT, env) == ref, env

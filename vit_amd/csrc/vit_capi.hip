@@ -376,7 +376,20 @@ int vit_num_chunks(const vit_ctx* ctx, int batch) {
     return k;
 }
 static int num_chunks(const vit_ctx* ctx, int batch) { return vit_num_chunks(ctx, batch); }
-static int chunk_begin(int batch, int k, int i) { return (int)((long)batch * i / k); }
+// First image of chunk i of k. Two chunks are cut 5 : 3, not in halves: equal chunks run the same kernels for the same
+// time on both streams, so their last tile rounds (the idle CUs the second stream is there to fill) coincide; unequal
+// chunks drift out of phase. Measured (tools/split_sweep.sh, one box): ViT-B/16 batch 256 9.00 ms at 50 %, 8.74 at 58 %,
+// 8.67 at 62 %, 8.70 at 64 %, 8.75 at 70 %; CLIP-L/14-336 batch 128 and ViT-H/14-448 batch 32: -0.3 % .. -0.8 %.
+// Lab switch VIT_AMD_SPLIT_PCT: share of the batch in the first chunk, in percent.
+int vit_chunk_begin(int batch, int k, int i) {
+    static const int pct = getenv("VIT_AMD_SPLIT_PCT") ? atoi(getenv("VIT_AMD_SPLIT_PCT")) : 62;
+    if (k == 2 && i == 1 && pct > 0 && pct < 100) {
+        const int b = (int)(((long)batch * pct + 50) / 100);
+        return b < 1 ? 1 : (b > batch - 1 ? batch - 1 : b);
+    }
+    return (int)((long)batch * i / k);
+}
+static int chunk_begin(int batch, int k, int i) { return vit_chunk_begin(batch, k, i); }
 
 extern "C" size_t vit_workspace_bytes(const vit_ctx* ctx, int batch) {
     if (!ctx || batch <= 0) return 0;

@@ -23,6 +23,7 @@ int launch_convert_2d(const void* src, int sdt, void* dst, int ddt, int64_t rows
 
 extern "C" int vit_train_refresh_transposes(vit_ctx* ctx, void* stream_);
 int vit_num_chunks(const vit_ctx* ctx, int batch);  // vit_capi.hip: the stream split rule of vit_forward
+int vit_chunk_begin(int batch, int k, int i);        // vit_capi.hip: first image of chunk i of k (two chunks: 5 : 3)
 
 struct TrainState {
     float* master = nullptr;        // fp32 master copy of every parameter, gradient-arena layout
@@ -379,11 +380,11 @@ extern "C" int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel
     ctx->train->fwd_batch = batch;
     ctx->train->fwd_pixel_dtype = pixel_dtype;
     ctx->train->fwd_stash = stash_;
-    // as vit_forward: two halves on two streams, so one half's kernels fill the CUs the other half's last
+    // as vit_forward: two chunks on two streams, so one chunk's kernels fill the CUs the other's last
     // round of GEMM tiles leaves idle (the stash keeps its single-batch layout)
     const int k = vit_num_chunks(ctx, batch) >= 2 ? 2 : 1;
     if (k == 1) return run(0, batch, stream);
-    const int h0 = (batch + 1) / 2;
+    const int h0 = vit_chunk_begin(batch, 2, 1);
     VIT_CHECK_HIP(hipEventRecord(ctx->ev_fork, stream));
     VIT_CHECK_HIP(hipStreamWaitEvent(ctx->aux_stream[0], ctx->ev_fork, 0));
     // from here on the side stream is joined back whatever happens (an error must not leave it running)
