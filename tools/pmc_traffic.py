@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --output-format csv) of
 `VIT_AMD_STREAMS=1 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernels` into the per-launch
-averages bench.py reads (profiles/r02b_traffic.json).
+averages bench.py reads (profiles/r02d_traffic.json).
 
-  python tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/r02b_traffic.json
+  python tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/r02d_traffic.json
 
 Only library kernels are kept, grouped by the bench's kernel names; launches of the same kernel on other shapes
 (the pooled-row LayerNorm) are dropped by their grid size."""
