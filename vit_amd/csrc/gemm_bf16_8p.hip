@@ -544,8 +544,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                             v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
                         }
                         if constexpr (EPI == VIT_EPI_QUICK_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = apply_act_bf16<EPI>(v[e]);
+                            const f32x2 g0 = act_quick_gelu_pk(f32x2{v[0], v[1]}), g1 = act_quick_gelu_pk(f32x2{v[2], v[3]});
+                            v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
                         }
                         if constexpr (USES_RES) {
                             const bf16x4 r = __builtin_bit_cast(bf16x4, rres[ha * 16 + mi * 4 + j]);

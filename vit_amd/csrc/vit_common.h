@@ -105,9 +105,18 @@ __device__ __forceinline__ f32x2 act_dgelu_pk(f32x2 x) {
 }
 __device__ __forceinline__ float act_dgelu_as(float x) { return act_dgelu_pk(f32x2{x, x}).x; }
 __device__ __forceinline__ float act_dquick_gelu(float x) {
-    const float sg = 1.0f / (1.0f + __expf(-1.702f * x));
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (-1.702f * 1.4426950408889634f)));
     return sg * (1.0f + 1.702f * x * (1.0f - sg));
 }
+// quick_gelu of the bf16 kernels: x * rcp(1 + exp2(-1.702 log2(e) x)). The IEEE division of act_quick_gelu is a dozen
+// instructions per element (v_div_scale x2, v_rcp, five fmas, v_div_fmas, v_div_fixup); v_rcp_f32 alone is good to
+// 1 ulp of fp32, far below the bf16 rounding of the stored activation. The fp32 kernels keep the division.
+__device__ __forceinline__ f32x2 act_quick_gelu_pk(f32x2 x) {
+    const f32x2 a = x * (-1.702f * 1.4426950408889634f);
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + 1.0f;
+    return x * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ float act_quick_gelu_fast(float x) { return act_quick_gelu_pk(f32x2{x, x}).x; }
 // multiplier of the backward epilogues: d act(aux) / d aux
 template <int EPI>
 __device__ __forceinline__ float act_grad(float aux) {
@@ -119,7 +128,7 @@ __device__ __forceinline__ float act_grad(float aux) {
 template <int EPI>
 __device__ __forceinline__ float apply_act_bf16(float v) {
     if constexpr (EPI == VIT_EPI_GELU) return act_gelu_poly(v);
-    if constexpr (EPI == VIT_EPI_QUICK_GELU) return act_quick_gelu(v);
+    if constexpr (EPI == VIT_EPI_QUICK_GELU) return act_quick_gelu_fast(v);
     return v;
 }
 
