@@ -3,6 +3,7 @@ import sys, torch
 sys.path.insert(0, ".")
 from vit_amd import ops, synth
 cases = [(32, 1025, 16, 80), (64, 577, 16, 64), (256, 197, 12, 64), (8, 1025, 16, 80)]
+if len(sys.argv) > 1: cases = [cases[int(i)] for i in sys.argv[1:]]   # e.g. "2" = the ViT-B/16 case only (counter runs)
 for b, n, h, dh in cases:
     qkv = synth.normal((b, n, 3 * h * dh), 3, "qkv", device="cuda:0").to(torch.bfloat16)
     for _ in range(3): ops.attention(qkv, h)
