@@ -107,7 +107,7 @@ size_t vit_workspace_bytes(const vit_ctx* ctx, int batch);
  *   pooled_out   [batch, D]    in the context dtype  (ViT: CLS row of hidden_out;
  *                CLIP: post_layernorm of the CLS row). May be NULL.
  *   workspace    >= vit_workspace_bytes(ctx, batch) bytes, 256-byte aligned.
- * VIT_BF16 contexts run batches of >= 2 x 6304 token rows (2 x 32 images at 197 tokens) as two contiguous halves, one on `stream` and one on
+ * VIT_BF16 contexts run batches of >= 2 x 6304 token rows (2 x 32 images at 197 tokens) as two contiguous chunks (5 : 3 of the batch: DESIGN.md 3.5), one on `stream` and one on
  * a stream the context owns (forked from and joined back into `stream` with events, so the call
  * keeps its stream semantics and stays graph-capturable): one half's kernels occupy the CUs the
  * other half's last round of GEMM tiles leaves idle (+5 % images/s at ViT-B/16 batch 256).
@@ -241,7 +241,7 @@ int vit_grad_layer_range(vit_ctx* ctx, int layer, size_t* offset_bytes, size_t* 
 int vit_train_init(vit_ctx* ctx, void* stream);
 int vit_train_refresh_transposes(vit_ctx* ctx, void* stream);
 /* vit_forward that also fills `stash` (ViTModel.forward MV:356-388 with every intermediate kept).
- * Like vit_forward it runs big enough batches as two halves on two streams. */
+ * Like vit_forward it runs big enough batches as two chunks on two streams. */
 int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
                       void* pooled_out, void* stash, size_t stash_bytes, void* workspace, size_t workspace_bytes,
                       void* stream);

@@ -155,7 +155,7 @@ def test_determinism_repeat_runs():
 
 @pytest.mark.gpu
 def test_two_stream_forward_equals_single_stream(monkeypatch):
-    """vit_forward cuts batches >= 64 into two halves on two streams (VIT_AMD_STREAMS, read at vit_create).
+    """vit_forward cuts batches >= 64 into two chunks (5 : 3) on two streams (VIT_AMD_STREAMS, read at vit_create).
     Images are independent and the kernels deterministic: the outputs must be bit-identical to the
     single-stream run, for an odd batch (uneven halves) and back-to-back calls on the same workspace."""
     import torch

@@ -57,7 +57,7 @@ struct vit_ctx {
     size_t g_patch_w, g_patch_b, g_cls, g_pos, g_pre_g, g_pre_b, g_fin_g, g_fin_b;
     std::vector<LayerG> glayers;
     TrainState* train;
-    // two-stream forward (vit_capi.hip): the two halves of a batch run on the caller's stream and on
+    // two-stream forward (vit_capi.hip): the two chunks of a batch run on the caller's stream and on
     // aux_stream, so one half's kernels fill the CUs the other half's last tile round leaves idle
     static const int kMaxStreams = 4;
     hipStream_t aux_stream[kMaxStreams - 1];
