@@ -281,3 +281,53 @@ def test_layer_norm_stats_and_folded_gemm_are_row_position_independent():
     out = ops.linear_ln_folded(x, folded, st)
     assert torch.equal(ops.linear_ln_folded(x, folded, st), out)
     assert torch.equal(ops.linear_ln_folded(x[perm].contiguous(), folded, st[perm].contiguous()), out[perm])
+
+
+def _all_bf16_values(lo, hi, count):
+    """every finite bf16 value in [lo, hi], tiled to `count` entries (the GEMM below passes them through unchanged)"""
+    bits = torch.arange(0, 1 << 16, dtype=torch.int32).to(torch.int16)
+    v = bits.view(torch.bfloat16)
+    v = v[torch.isfinite(v.float()) & (v.float() >= lo) & (v.float() <= hi)]
+    reps = (count + v.numel() - 1) // v.numel()
+    return v.repeat(reps)[:count]
+
+
+@pytest.mark.parametrize("act", ["gelu", "quick_gelu"])
+def test_activation_epilogue_error_bound_on_every_bf16_input(act):
+    """The persistent GEMM's activation epilogues against the exact functions (fp64) on EVERY bf16 value in [-12, 12]:
+    A holds the values, W is the identity, so the pre-activation is the value itself. gelu is the packed polynomial of
+    vit_common.h (|error| <= 8.5e-5 stated there) and quick_gelu the v_rcp form; on top of that the output is rounded
+    to bf16 once (half an ulp of the result)."""
+    m, n = 16384, 256  # m * n = 64 * 256 * 256: the smallest problem the persistent kernel takes
+    a = _all_bf16_values(-12.0, 12.0, m * n).view(m, n).to(DEV)
+    w = torch.eye(n, dtype=torch.bfloat16, device=DEV)
+    y = ops.linear(a, w, None, activation=act).double().cpu()
+    x = a.double().cpu()
+    if act == "gelu":
+        want = 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+        fn_err = 8.5e-5
+    else:
+        want = x * torch.sigmoid(1.702 * x)
+        fn_err = 1e-6 * want.abs() + 1e-30
+    half_ulp = want.abs() * 2.0 ** -8  # bf16: 8 significant bits, so half an ulp <= 2^-9 * 2^ceil(log2) <= 2^-8 |y|
+    err = (y - want).abs()
+    assert bool((err <= fn_err + half_ulp + 1e-38).all()), float((err - fn_err - half_ulp).max())
+    assert float(y[x >= 6].sub(x[x >= 6]).abs().max()) == 0.0  # upper tail: act(x) rounds to x
+    if act == "gelu":
+        assert float(y[x <= -9].abs().max()) == 0.0            # lower tail: Phi is clamped to exactly 0
+
+
+def test_gelu_backward_multiplier_error_bound_on_every_bf16_input():
+    """gelu'(aux) of the data-gradient epilogue (VIT_EPI_DGELU) on every bf16 aux in [-12, 12]: dY W = 1 everywhere, so the
+    output is the multiplier itself, Phi(x) + x phi(x)."""
+    m, n, k = 16384, 256, 256
+    aux = _all_bf16_values(-12.0, 12.0, m * n).view(m, n).to(DEV)
+    dy = torch.zeros(m, k, dtype=torch.bfloat16, device=DEV)
+    dy[:, 0] = 1.0
+    wt = torch.zeros(n, k, dtype=torch.bfloat16, device=DEV)
+    wt[:, 0] = 1.0
+    g = ops.linear_dgrad(dy, wt, pre_activation=aux, activation="gelu").double().cpu()
+    x = aux.double().cpu()
+    want = 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
+    err = (g - want).abs()
+    assert float((err - want.abs() * 2.0 ** -8).max()) <= 6e-5  # Phi from the polynomial: <= 4.3e-5; exp2 / rounding on top
