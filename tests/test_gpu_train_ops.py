@@ -112,6 +112,7 @@ def test_attention_backward(b, n, h, dh):
 @pytest.mark.parametrize("tokens,out_f,in_f,splits", [
     (51, 64, 128, 1),        # fewer tokens than one 64-token tile: rows past T must read as zero
     (64, 8, 8, 1),           # smallest legal features
+    (50, 264, 520, 1), (64, 256, 256, 1), (130, 256, 512, 2),  # two or three 32-token slots per split: the ring's prologue covers the whole loop
     (197 * 3, 768, 768, 1),  # ragged tokens, exact 256-tiles
     (1000, 264, 520, 3),     # ragged tiles in both feature dims, splits that do not divide the token count
     (4096, 2304, 768, 4), (8320, 768, 3072, 7), (8320, 3072, 768, 5),
