@@ -18,6 +18,11 @@ def load_golden(name):
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a-b| / max |b| : the 'relative error' of BASELINE.json's fp32 bar."""
+    if a.is_cuda and b.is_cuda and a.numel() > (1 << 24):
+        # whole bench-shape matrices: the subtraction and the two maxima run where the data is (plain torch
+        # elementwise ops in fp32 on exact bf16 / fp32 inputs; no 2 x 2.4 GB host copies per comparison)
+        a, b = a.float(), b.float()
+        return ((a - b).abs().max().double() / b.abs().max().double().clamp_min(1e-30)).item()
     a, b = a.double().cpu(), b.double().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 

@@ -22,6 +22,12 @@ DEV = "cuda:0"
 BF16_TOL = 1.0 / 128
 SHAPES = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]  # (N, K): q/k/v, o_proj, fc1, fc2 of ViT-B/16
 MS = [50432, 50431]
+# configs[2] / [3] at the batch they are benched at: CLIP-L/14-336 batch 128 (M = 128 * 577) and ViT-H/14-448 batch 32
+# (M = 32 * 1025), each with a ragged M as well; (M, N, K) for q/k/v, o_proj, fc1, fc2
+L14_M, H14_M = 128 * 577, 32 * 1025
+BIG = [(m, n, k) for m in (L14_M, L14_M - 1) for (n, k) in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096))] + \
+      [(m, n, k) for m in (H14_M, H14_M - 1) for (n, k) in ((3840, 1280), (1280, 1280), (5120, 1280), (1280, 5120))]
+ALL_MNK = [(m, n, k) for (n, k) in SHAPES for m in MS] + BIG
 
 
 def gen(shape, name, std=1.0):
@@ -48,8 +54,7 @@ def check(out, ref_full, x, w, bias, post, rows):
     assert rel_err(out[rows.to(DEV)], o) < BF16_TOL
 
 
-@pytest.mark.parametrize("n,k", SHAPES)
-@pytest.mark.parametrize("m", MS)
+@pytest.mark.parametrize("m,n,k", ALL_MNK)
 def test_forward_epilogues_at_bench_shapes(m, n, k):
     x, w = gen((m, k), "x"), gen((n, k), "w", 1 / math.sqrt(k))
     bias = synth.normal((n,), 23, "b", 0.5, device=DEV)
@@ -72,14 +77,15 @@ def test_forward_epilogues_at_bench_shapes(m, n, k):
     check(out, ref, x, w, bias, lambda y, r=None: vit_oracle.activation(y, "gelu"), rows)
 
 
-@pytest.mark.parametrize("n,k", [(2304, 768), (3072, 768)])
-@pytest.mark.parametrize("m", MS)
+@pytest.mark.parametrize("m,n,k", [(m, n, k) for (n, k) in ((2304, 768), (3072, 768)) for m in MS] +
+                         [(m, n, k) for m in (L14_M, L14_M - 1) for (n, k) in ((3072, 1024), (4096, 1024))] +
+                         [(m, n, k) for m in (H14_M, H14_M - 1) for (n, k) in ((3840, 1280), (5120, 1280))])
 def test_folded_layernorm_gemm_at_bench_shapes(m, n, k):
     """LN1 -> q/k/v and LN2 -> fc1 as vit_forward runs them: statistics pass + GEMM on the un-normalised rows."""
     x = (gen((m, k), "x").float() * 1.5 + 0.3).to(torch.bfloat16)
     w, bias = gen((n, k), "w", 1 / math.sqrt(k)), synth.normal((n,), 23, "b", 0.5, device=DEV)
     g, b = synth.normal((k,), 23, "g", 0.1, 1.0, device=DEV), synth.normal((k,), 23, "beta", 0.1, device=DEV)
-    eps = 1e-12
+    eps = 1e-5 if k == 1024 else 1e-12  # CLIP / ViT (configuration_clip.py:106, configuration_vit.py:58)
     stats = ops.layer_norm_stats(x, eps)
     folded = ops.layer_norm_fold(w, g, b, bias)
     rows = sample_rows(m)

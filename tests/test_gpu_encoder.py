@@ -104,6 +104,45 @@ def test_full_batch_properties_vit_b16_bf16():
     assert min_row_cosine(out.pooler_output[idx], ref) >= 0.999
 
 
+@pytest.mark.parametrize("name,batch,subs,oracle_rows", [
+    ("clip_l14_336", 128, ((40, 48), (101, 103)), (0, 77, 127)),   # BASELINE.json configs[2], the batch it is benched at
+    ("vit_h14_448", 32, ((8, 16), (30, 32)), (0, 21)),             # configs[3]: batch per GPU of the bench line
+])
+def test_full_batch_properties_large_configs_bf16(name, batch, subs, oracle_rows):
+    """CLIP-L/14-336 at batch 128 and ViT-H/14-448 at batch 32 -- what bench.py times for configs[2] / [3]: the
+    persistent GEMM at K = 1024 / 4096 / 1280 / 5120 with quick_gelu / gelu and folded LayerNorm, the 5 : 3 two-stream
+    cut at 577 / 1025 tokens, the dense patch-row route (P = 14) and the dh-64 / dh-80 ring attention kernels with many
+    items per workgroup. Size-independent properties: finite; a permuted batch gives the permuted output bit for bit;
+    an 8-image and a 2-image sub-batch are bit-equal to the same rows of the full batch (ties the full-batch path to
+    the golden-checked small-batch path: 2 images run the generic kernels on one stream); and a few CLS rows against
+    the CPU oracle on bf16-rounded weights, cosine >= 0.999 with the max-abs error printed (modeling_clip.py:362-383,
+    641-656; modeling_vit.py:266-286, 385)."""
+    cfg, _, _ = load_golden(name)
+    enc = build(cfg, torch.bfloat16)
+    px = synth.synthetic_images(cfg, batch, seed=2, device=DEV).to(torch.bfloat16)
+    out = enc(px)
+    hidden, pooled = out.last_hidden_state.clone(), out.pooler_output.clone()
+    assert torch.isfinite(hidden).all() and torch.isfinite(pooled).all()
+    perm = torch.randperm(batch, generator=torch.Generator().manual_seed(0)).to(DEV)
+    out_p = enc(px[perm].contiguous())
+    assert torch.equal(out_p.pooler_output, pooled[perm])
+    assert torch.equal(out_p.last_hidden_state, hidden[perm])
+    del out_p
+    for lo, hi in subs:
+        out_s = enc(px[lo:hi].contiguous())
+        assert torch.equal(out_s.last_hidden_state, hidden[lo:hi]), (lo, hi)
+        assert torch.equal(out_s.pooler_output, pooled[lo:hi]), (lo, hi)
+    sd = vit_oracle.quantize_state_dict_bf16(synth.synthetic_state_dict(cfg, seed=0))
+    idx = list(oracle_rows)
+    _, ref = vit_oracle.forward(px[idx].float().cpu(), sd, cfg)
+    got = pooled[idx].float().cpu()
+    cos = min_row_cosine(got, ref)
+    print(f"{name} bf16 batch {batch}: CLS min cosine {cos:.6f}, max-abs {(got - ref).abs().max():.4f} "
+          f"(reference max-abs {ref.abs().max():.3f})")
+    assert cos >= 0.999
+    enc.close()
+
+
 def test_hf_prefixes_and_bf16_sources_accepted():
     cfg, batch, fx = load_golden("tiny_vit_p8")
     sd = {"vit." + k: v.to(torch.bfloat16) for k, v in synth.synthetic_state_dict(cfg, seed=0).items()}

@@ -192,6 +192,40 @@ def test_attention_online_softmax_rescale_branch(dtype):
     assert rel_err(out, ref) < (2e-5 if dtype == torch.float32 else 2 * BF16_TOL)
 
 
+# head_dim 80 ring kernel with MORE items than resident workgroups (nmy > 1: the item-boundary code -- the counted
+# waits with the previous item's stores and the Q prefetch in flight, the DMA cursor crossing into the next item's
+# K / V, the o / m / l reset): 8 waves x 640 items (two workgroups per CU: 512 resident), 12 waves x 576 items of
+# 1025 tokens (the ViT-H/14 shape; 256 resident; the third query block has 9 of 12 waves with queries), 11 waves x 288
+# items whose second query block has one wave without queries, 8 waves x 2 query blocks x 640 items.
+RING_MULTI_ITEM = [(40, 193, 16, 80), (12, 1025, 16, 80), (9, 660, 16, 80), (20, 512, 16, 80)]
+
+
+@pytest.mark.parametrize("b,n,h,dh", RING_MULTI_ITEM)
+@pytest.mark.parametrize("train", [False, True])
+def test_attention_ring_kernel_many_items_per_workgroup(b, n, h, dh, train):
+    qkv = q(rnd((b, n, 3 * h * dh), "ring.qkv", 1.5))
+    d = h * dh
+    qh, kh, vh = [t.reshape(b, n, h, dh).transpose(1, 2) for t in qkv.split(d, dim=-1)]
+    s = (qh @ kh.transpose(2, 3)) * dh ** -0.5
+    ref = (torch.softmax(s, dim=-1) @ vh).transpose(1, 2).reshape(b, n, d)
+    x = qkv.to(DEV, torch.bfloat16)
+    if train:
+        out, lse = ops.attention_train(x, h)
+        ref_lse = torch.logsumexp(s, -1) / math.log(2.0)
+        assert (lse.cpu() - ref_lse).abs().max() <= 2e-2
+        out2, lse2 = ops.attention_train(x, h)
+        assert torch.equal(lse, lse2)
+    else:
+        out = ops.attention(x, h)
+        out2 = ops.attention(x, h)
+    assert torch.equal(out, out2)  # repeatable: a miscounted wait shows as run-to-run differences first
+    assert rel_err(out, ref) < 2 * BF16_TOL
+    # per (batch, head) block, so that one bad item cannot hide in the whole-tensor norm
+    err = (out.float().cpu() - ref).reshape(b, n, h, dh).abs().amax(dim=(1, 3))
+    scale = ref.reshape(b, n, h, dh).abs().amax(dim=(1, 3))
+    assert bool((err <= 2 * BF16_TOL * scale + 1e-3).all()), float((err / scale).max())
+
+
 def test_attention_uniform_scores_average_values():
     # q = 0 -> uniform softmax -> every output row is the mean of V (exact property)
     b, n, h, dh = 2, 197, 3, 64
