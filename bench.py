@@ -204,6 +204,66 @@ def train_main(args, cfg, enc, px, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def other_configs(dev, steps: int = 5, warm: int = 2):
+    """The BASELINE.json configurations the headline line does not time, measured on this GPU after the timed region
+    (one GPU, inputs resident, `steps` timed steps after `warm` untimed ones, a fresh encoder each, freed afterwards):
+    configs[2] at its global batch of 128 and at the 16 images a rank holds when that batch is sharded over 8 GPUs,
+    configs[3] at its per-GPU batch, and the configs[4] training step. Same timing rule as the headline loop."""
+    import gc
+    out = {}
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, r
+
+    for key, cname, batch in (("l14_b128", "l14", 128), ("l14_b16", "l14", 16), ("h14", "h14", CONFIGS["h14"][4])):
+        cfg = CONFIGS[cname][0]()
+        enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=dev)
+        enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0, device=dev))
+        px = synth.synthetic_images(cfg, batch, seed=1, device=dev).to(torch.bfloat16)
+        dt, o = timed(lambda: enc(px))
+        assert torch.isfinite(o.pooler_output).all(), key
+        out[key] = {"workload": f"{CONFIGS[cname][1]} bf16 forward, batch {batch} on one MI355X ({CONFIGS[cname][2]})",
+                    "ms_per_step": 1e3 * dt, "images_per_sec": batch / dt,
+                    "end_to_end_frac": batch / dt * cfg.flops_per_image() / MFMA_BF16_PEAK, "steps": steps}
+        enc.close()
+        del enc, px, o
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    from vit_amd.trainer import ViTTrainer
+    cfg = ViTConfig.vit_b16_224()
+    enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=dev)
+    enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0, device=dev))
+    tr = ViTTrainer(enc)
+    px = synth.synthetic_images(cfg, LOCAL_BATCH, seed=1, device=dev).to(torch.bfloat16)
+    target = synth.normal((LOCAL_BATCH, cfg.hidden_size), 7, "target", device=dev)
+
+    def train_step():
+        o = tr.forward(px)
+        d = (o.pooler_output.float() - target).mul_(1.0 / LOCAL_BATCH).to(torch.bfloat16)
+        tr.backward(None, d)
+        tr.sgd_step(1e-3)
+        return o
+
+    dt, o = timed(train_step)
+    assert torch.isfinite(o.pooler_output).all(), "train_b16"
+    out["train_b16"] = {"workload": "ViT-B/16 224^2 bf16 training step (forward + backward + SGD), batch 256 on one MI355X (configs[4])",
+                        "ms_per_step": 1e3 * dt, "images_per_sec": LOCAL_BATCH / dt,
+                        "end_to_end_frac": LOCAL_BATCH / dt * 3 * cfg.flops_per_image() / MFMA_BF16_PEAK, "steps": steps}
+    enc.close()
+    del tr, enc, px, o
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 CONFIGS = {
     # key: (ViTConfig factory, short name, BASELINE.json config, default scaling, default batch
     #       [weak: images per GPU; strong: global images])
@@ -236,6 +296,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of configs[2..4] that the default headline line appends as other_configs")
     ap.add_argument("--workload", choices=("forward", "train"), default="forward",
                     help="forward = the headline metric (BASELINE.json configs[1]); train = fwd+bwd+SGD step with the "
                          "gradient all-reduce (configs[4]), reported as images/sec of the training step")
@@ -336,6 +398,11 @@ def main():
                                 "traffic": pmc_traffic_bytes(dom) if (args.config == "b16" and local_batch == LOCAL_BATCH) else None,
                                 "kernel": "bf16 MFMA GEMM (" + dom + ")", "us_per_launch": r["us_per_launch"]}
             line["kernels"] = ks
+        if world == 1 and args.config == "b16" and not args.no_other_configs:
+            enc.close()
+            del enc, px, out
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ViTConfig.vit_b16_224())
         print(json.dumps(line), flush=True)

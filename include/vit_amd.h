@@ -79,7 +79,11 @@ typedef struct vit_config {
 
 /* ---- library ---- */
 const char* vit_last_error(void);
-/* ABI version: bumped when a signature changes. */
+/* ABI version: bumped when an entry point is added or a signature changes. History: 1 = inference path and
+ * per-kernel entry points; 2 = + training step, folded LayerNorm, heads, preprocessing, position interpolation,
+ * vit_forward_static; 3 = vit_backward_stage accepts any stash that a vit_forward_train of this context filled
+ * (several in flight), few-tile GEMM route. The library returns the VIT_ABI_VERSION it was built with. */
+#define VIT_ABI_VERSION 3
 int vit_abi_version(void);
 
 /* ---- context: weights live in one arena allocated here (NOT on the hot path) ---- */

@@ -124,6 +124,14 @@ def test_resized_clone_follows_weight_changes():
     # the clone of the updated encoder equals a clone made from scratch now
     enc.weights_changed()
     assert torch.equal(c, enc(px, interpolate_pos_encoding=True).pooler_output)
+    # (3) a clone the caller HOLDS stays a valid object across weight changes: its next forward refreshes it
+    held = enc.with_image_size(48)
+    enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=5))
+    assert torch.equal(held(px).pooler_output, b)
+    assert enc.with_image_size(48) is held
+    enc.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        enc(p32)
 
 
 def test_trainer_rejects_heads_and_pooler_keys_are_skipped():

@@ -149,3 +149,38 @@ def test_split_k_weight_gradients_match_autograd():
         torch.cuda.synchronize()
         for k, g in first.items():
             assert torch.equal(tr.grad(k), g), k
+
+
+def test_two_stashes_in_flight_and_unknown_stash_rejected():
+    """Micro-batching: two vit_forward_train calls into two stashes, then their backwards in the other order. Each
+    backward must give the gradients of a plain forward + backward of the same micro-batch bit for bit (matrix
+    gradients take no atomics), and a stash that no vit_forward_train of this context filled is refused."""
+    from vit_amd import _lib
+    cfg, batch, _ = load_golden("tiny_vit_p16_n197")
+    sd = vit_oracle.quantize_state_dict_bf16(synth.synthetic_state_dict(cfg, seed=0))
+    px = [synth.synthetic_images(cfg, batch, seed=s).to(torch.bfloat16) for s in (1, 2)]
+    w_p = synth.normal((batch, cfg.hidden_size), 5, "wp", 0.5).to(torch.bfloat16)
+    enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
+    enc.load_state_dict(sd)
+    tr = ViTTrainer(enc)
+    key = ("layers.1.mlp.fc1.weight", "layers.0.attention.q_proj.weight", "layers.1.attention.o_proj.weight")
+    want = []
+    for p in px:
+        tr.forward(p)
+        tr.backward(None, w_p)
+        torch.cuda.synchronize()
+        want.append({k: tr.grad(k).clone() for k in key})
+    held = []
+    for p in px:
+        tr._stash = None  # a fresh stash per micro-batch, both alive
+        tr.forward(p)
+        held.append((tr._stash, tr._px))
+    for i in (1, 0):
+        tr._stash, tr._px = held[i]
+        tr.backward(None, w_p)
+        torch.cuda.synchronize()
+        for k in key:
+            assert torch.equal(tr.grad(k), want[i][k]), (i, k)
+    tr._stash = torch.empty_like(held[0][0])
+    with pytest.raises(_lib.VitError, match="was not filled"):
+        tr.backward(None, w_p)

@@ -73,7 +73,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()  # raises if the .so or any symbol is missing
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.vit_abi_version() == 1
+    assert lib.vit_abi_version() == 3  # VIT_ABI_VERSION of include/vit_amd.h
 
 
 def test_argument_errors_need_no_gpu():

@@ -332,10 +332,11 @@ int launch_attn_bf16(const void* qkv, void* out, float* lse, int batch, int N, i
     if (KC > kcmax) KC = kcmax;
     const size_t lds = (size_t)KC * (G::KS + G::VS);
     auto kern = attention_bf16_kernel<DH>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceInt attr_set;  // per instantiation and device
+    std::atomic<int>* as = attr_set.slot();
+    if (!as || !as->load(std::memory_order_relaxed)) {
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
+        if (as) as->store(1, std::memory_order_relaxed);
     }
     const float scale_log2e = LOG2E / sqrtf((float)DH);
     hipLaunchKernelGGL(kern, dim3(batch * H, qblocks), dim3(waves * 64), lds, stream, (const bf16_t*)qkv, (bf16_t*)out,
@@ -355,10 +356,11 @@ int launch_attn_f32(const void* qkv, void* out, int batch, int N, int H, hipStre
     if (KC > kcmax) KC = kcmax;
     const size_t lds = (size_t)KC * per_key;
     auto kern = attention_f32_kernel<DH>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceInt attr_set;  // per instantiation and device
+    std::atomic<int>* as = attr_set.slot();
+    if (!as || !as->load(std::memory_order_relaxed)) {
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
+        if (as) as->store(1, std::memory_order_relaxed);
     }
     const float scale_log2e = LOG2E / sqrtf((float)DH);
     hipLaunchKernelGGL(kern, dim3(batch * H, qblocks), dim3(waves * 64), lds, stream, (const float*)qkv, (float*)out, N,

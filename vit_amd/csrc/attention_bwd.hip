@@ -426,13 +426,14 @@ int launch_bwd_part(const void* qkv, const void* dO, const float* lse, const flo
     size_t lds = (size_t)IC * per_row;
     if (lds < (size_t)waves * 32 * G::RS) lds = (size_t)waves * 32 * G::RS;  // the store epilogue's per-wave blocks
     auto kern = attn_bwd_kernel<DH, MODE>;
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        VIT_CHECK_HIP(hipGetDevice(&dev));
+    static PerDeviceInt attr_set;  // per instantiation and device
+    std::atomic<int>* as = attr_set.slot();
+    if (!as || !as->load(std::memory_order_relaxed)) {
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX + 8 * 1024));
-        VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (as) as->store(1, std::memory_order_relaxed);
     }
+    int ncu = 0;
+    VIT_TRY_RC(vit_cu_count(&ncu));
     int per_cu = 1;
     VIT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, threads, lds));
     if (per_cu < 1) per_cu = 1;

@@ -366,13 +366,15 @@ int launch_attention_dh64(const void* qkv, void* out, float* lse, int batch, int
     const long nitems = (long)batch * H * qblocks;
     VIT_REQUIRE(nitems < (1L << 31), "attention: too many (batch, head, query block) items");
     VIT_REQUIRE((long)N * 3 * H * DH * 2 < (1L << 31), "attention: one image's qkv rows exceed 2 GiB");
-    static int resident = 0;
+    static PerDeviceInt resident_of;  // resident workgroups, per device
+    std::atomic<int>* rs = resident_of.slot();
+    int resident = rs ? rs->load(std::memory_order_relaxed) : 0;
     if (resident == 0) {
-        int dev, cus, per_cu = 0;
-        VIT_CHECK_HIP(hipGetDevice(&dev));
-        VIT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        int cus, per_cu = 0;
+        VIT_TRY_RC(vit_cu_count(&cus));
         VIT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)attention_dh64_kernel<false>, NW * 64, 0));
         resident = cus * (per_cu > 0 ? per_cu : 1);
+        if (rs) rs->store(resident, std::memory_order_relaxed);
     }
     const int grid = nitems < resident ? (int)nitems : resident;
     const float scale_log2e = LOG2E / sqrtf((float)DH);

@@ -295,10 +295,11 @@ template <int BN, int AMODE, int EPI, bool LNF = false>
 int launch_one(const GemmParams& P, hipStream_t stream) {
     using G = Geo<BN>;
     auto kern = gemm_bf16_kernel<BN, AMODE, EPI, LNF>;
-    static bool attr_set = false;  // per instantiation; the attribute is idempotent
-    if (!attr_set) {
+    static PerDeviceInt attr_set;  // per instantiation and device; the attribute is idempotent
+    std::atomic<int>* as = attr_set.slot();
+    if (!as || !as->load(std::memory_order_relaxed)) {
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-        attr_set = true;
+        if (as) as->store(1, std::memory_order_relaxed);
     }
     const int MT = ceil_div(P.M, BM);
     dim3 grid(MT * P.NT), block(NTHREADS);

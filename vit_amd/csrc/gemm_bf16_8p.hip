@@ -611,10 +611,11 @@ inline int group_cols(int NT, int K) {
 template <int EPI, int OUTM, bool LNF = false>
 int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
     auto kern = gemm8p_persist_kernel<EPI, OUTM, LNF>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceInt attr_set;  // per instantiation and device
+    std::atomic<int>* as = attr_set.slot();
+    if (!as || !as->load(std::memory_order_relaxed)) {
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 4096));
-        attr_set = true;
+        if (as) as->store(1, std::memory_order_relaxed);
     }
     const int G = P.T < ncu ? P.T : ncu;
     hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), LDS_BYTES + 4096, stream, P);
@@ -647,12 +648,8 @@ unsigned long long* g8_stamps = nullptr;  // lab: device buffer of 8 stamps per 
 int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
                         int epi, const GemmExt* ext, hipStream_t stream) {
     VIT_REQUIRE(gemm_bf16_8p_eligible(M, N, K), "gemm8p: shape M=%d N=%d K=%d not eligible", M, N, K);
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        VIT_CHECK_HIP(hipGetDevice(&dev));
-        VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    VIT_TRY_RC(vit_cu_count(&ncu));
     g8::PParams P{};
     P.A = (const bf16_t*)A; P.W = (const bf16_t*)W; P.bias = bias; P.res = (const bf16_t*)res; P.C = (bf16_t*)C;
     P.Cpre = ext ? (bf16_t*)ext->c_pre : nullptr;
@@ -706,12 +703,8 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
 int launch_gemm_bf16_8p_patch(const void* pixels, const void* W, const float* bias, const float* pos, void* C, int M, int N,
                               const PatchGeom* g, hipStream_t stream) {
     VIT_REQUIRE(gemm_bf16_8p_patch_eligible(M, N, g), "gemm8p: patch geometry not eligible");
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        VIT_CHECK_HIP(hipGetDevice(&dev));
-        VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    VIT_TRY_RC(vit_cu_count(&ncu));
     const int P = g->patch, K = g->channels * P * P;
     g8::PParams q{};
     q.A = (const bf16_t*)pixels; q.W = (const bf16_t*)W; q.bias = bias; q.C = (bf16_t*)C; q.pos = pos;
@@ -745,12 +738,8 @@ bool gemm_bf16_8p_patch_dense_eligible(int M, int N, int K, const PatchGeom* g) 
 int launch_gemm_bf16_8p_patch_dense(const void* A, const void* W, const float* bias, const float* pos, void* C, int M, int N,
                                     int K, const PatchGeom* g, hipStream_t stream) {
     VIT_REQUIRE(gemm_bf16_8p_patch_dense_eligible(M, N, K, g), "gemm8p: dense patch problem not eligible");
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        VIT_CHECK_HIP(hipGetDevice(&dev));
-        VIT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int ncu = 0;
+    VIT_TRY_RC(vit_cu_count(&ncu));
     g8::PParams q{};
     q.A = (const bf16_t*)A; q.W = (const bf16_t*)W; q.bias = bias; q.C = (bf16_t*)C; q.pos = pos;
     q.M = M; q.N = N; q.K = K; q.lda = K;

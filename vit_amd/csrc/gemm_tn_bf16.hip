@@ -217,10 +217,11 @@ int launch_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* db, flo
     VIT_REQUIRE(Mo % 8 == 0 && No % 8 == 0, "gemm_tn: feature counts must be multiples of 8 (Mo=%d No=%d)", Mo, No);
     VIT_REQUIRE((long)T * (Mo > No ? Mo : No) * 2 < (1L << 31), "gemm_tn: an operand exceeds 2 GiB");
     VIT_REQUIRE(splits == 1 || slabs != nullptr, "gemm_tn: split-K needs the slab scratch");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceInt attr_set;  // per device
+    std::atomic<int>* as = attr_set.slot();
+    if (!as || !as->load(std::memory_order_relaxed)) {
         VIT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+        if (as) as->store(1, std::memory_order_relaxed);
     }
     TnParams P{};
     P.A = (const bf16_t*)dY; P.B = (const bf16_t*)X; P.dbias = db;

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -74,18 +75,25 @@ struct ArenaBuilder {
 static __device__ __align__(256) unsigned char scratch[VIT_STATIC_SCRATCH_BYTES];
 static const int kMaxDevices = 64;
 static unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};
+static std::mutex g_scratch_mu;  // vit_create may be called from several threads (one context per device / stream)
 
 static int resolve_static_scratch(int device) {
     if (device < 0 || device >= kMaxDevices) return VIT_OK;  // vit_forward_static reports it when asked for
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (g_scratch_ptr[device]) return VIT_OK;
     void* p = nullptr;
     VIT_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     g_scratch_ptr[device] = (unsigned char*)p;
     return VIT_OK;
 }
+static unsigned char* static_scratch_of(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    return g_scratch_ptr[device];
+}
 
 extern "C" const char* vit_last_error(void) { return g_err; }
-extern "C" int vit_abi_version(void) { return 1; }
+extern "C" int vit_abi_version(void) { return VIT_ABI_VERSION; }
 
 extern "C" int vit_patch_kpad(int channels, int patch, int dtype) {
     const int k = channels * patch * patch;
@@ -111,7 +119,10 @@ extern "C" int vit_create(const vit_config* cfg, vit_ctx** out) {
 
     vit_ctx* ctx = new vit_ctx();
     ctx->cfg = c;
-    VIT_CHECK_HIP(hipGetDevice(&ctx->device));
+    if (hipError_t e0 = hipGetDevice(&ctx->device); e0 != hipSuccess) {
+        delete ctx;
+        return vit_set_error(VIT_E_HIP, "vit_create: hipGetDevice: %s", hipGetErrorString(e0));
+    }
     if (int rc = resolve_static_scratch(ctx->device); rc != VIT_OK) {
         delete ctx;
         return rc;
@@ -369,13 +380,25 @@ Workspace plan_workspace(const vit_ctx* ctx, int batch) {
 
 // A batch is cut into up to ctx->nstreams contiguous chunks of at least kMinChunkRows token rows (32 images of
 // 197 tokens: below that a chunk's GEMMs are too few tiles to be worth a stream), one stream each
+int vit_chunk_begin(int batch, int k, int i);
 int vit_num_chunks(const vit_ctx* ctx, int batch) {
     static const long kMinChunkRows = 32 * 197;
     int k = ctx->nstreams;
-    while (k > 1 && (long)(batch / k) * ctx->N < kMinChunkRows) --k;
+    // the SMALLEST chunk decides (two chunks are cut 5 : 3, vit_chunk_begin): below the minimum its N = D GEMMs fall
+    // under the persistent kernel's size threshold
+    auto smallest = [&](int kk) {
+        long m = batch;
+        for (int i = 0; i < kk; ++i) {
+            const long nb = vit_chunk_begin(batch, kk, i + 1) - vit_chunk_begin(batch, kk, i);
+            if (nb < m) m = nb;
+        }
+        return m;
+    };
+    while (k > 1 && smallest(k) * ctx->N < kMinChunkRows) --k;
     return k;
 }
 static int num_chunks(const vit_ctx* ctx, int batch) { return vit_num_chunks(ctx, batch); }
+int vit_chunk_begin(int batch, int k, int i);
 // First image of chunk i of k. Two chunks are cut 5 : 3, not in halves: equal chunks run the same kernels for the same
 // time on both streams, so their last tile rounds (the idle CUs the second stream is there to fill) coincide; unequal
 // chunks drift out of phase. Measured (tools/split_sweep.sh, one box): ViT-B/16 batch 256 9.00 ms at 50 %, 8.74 at 58 %,
@@ -495,10 +518,10 @@ extern "C" int vit_forward_static(vit_ctx* ctx, const void* pixels_dev, int pixe
     if (need > (size_t)VIT_STATIC_SCRATCH_BYTES)
         return vit_set_error(VIT_E_NOMEM, "vit_forward_static: batch %d needs %zu workspace bytes, the static scratch holds %zu "
                                           "(use vit_forward with a caller workspace)", batch, need, (size_t)VIT_STATIC_SCRATCH_BYTES);
-    if (ctx->device < 0 || ctx->device >= kMaxDevices || g_scratch_ptr[ctx->device] == nullptr)
+    unsigned char* const ptr = static_scratch_of(ctx->device);
+    if (ptr == nullptr)
         return vit_set_error(VIT_E_STATE, "vit_forward_static: no static scratch resolved for device %d", ctx->device);
-    return vit_forward(ctx, pixels_dev, pixel_dtype, batch, hidden_out, pooled_out, g_scratch_ptr[ctx->device],
-                       (size_t)VIT_STATIC_SCRATCH_BYTES, stream);
+    return vit_forward(ctx, pixels_dev, pixel_dtype, batch, hidden_out, pooled_out, ptr, (size_t)VIT_STATIC_SCRATCH_BYTES, stream);
 }
 
 // the whole forward of `batch` images on one stream

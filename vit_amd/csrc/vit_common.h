@@ -29,6 +29,42 @@ int vit_set_error(int code, const char* fmt, ...);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// One-time launch set-up is PER DEVICE (a function attribute is set on the current device's copy of the code object;
+// CU counts and occupancy are device properties): a `static PerDeviceInt` in a launcher holds one int per device,
+// 0 = nothing done yet on that device. Concurrent first launches from two threads write the same value (relaxed
+// atomics; hipFuncSetAttribute is idempotent).
+#include <atomic>
+struct PerDeviceInt {
+    static constexpr int kMax = 64;
+    std::atomic<int> v[kMax];
+    // slot of the current device, or nullptr (device id out of range / no current device: do the set-up every time)
+    std::atomic<int>* slot() {
+        int d = -1;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMax) return nullptr;
+        return &v[d];
+    }
+};
+// CU count of the current device (cached per device)
+static inline int vit_cu_count(int* ncu) {
+    static PerDeviceInt cache;
+    std::atomic<int>* s = cache.slot();
+    int n = s ? s->load(std::memory_order_relaxed) : 0;
+    if (n == 0) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return vit_set_error(VIT_E_HIP, "CU count: %s", hipGetErrorString(e));
+        if (s) s->store(n, std::memory_order_relaxed);
+    }
+    *ncu = n;
+    return VIT_OK;
+}
+#define VIT_TRY_RC(expr)              \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != VIT_OK) return _rc; \
+    } while (0)
+
 // ---- activations (fp32 math) ----
 __device__ __forceinline__ float act_gelu_erf(float x) {
     // exact GELU: 0.5 x (1 + erf(x / sqrt 2))   (configuration_vit.py:54, ACT2FN["gelu"])

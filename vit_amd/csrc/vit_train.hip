@@ -35,10 +35,12 @@ struct TrainState {
     int nconv = 0;
     TransposeSlot* tr_table = nullptr;  // device: the 4 transposed weights of every layer (vit_train_refresh_transposes)
     int ntr = 0, tr_blocks = 0;
-    // what the last vit_forward_train wrote into the caller's stash: every backward stage must be called with the same
-    // batch (the stash layout is derived from it) and, for the embedding stage, the same pixel dtype
-    int fwd_batch = 0, fwd_pixel_dtype = -1;
-    const void* fwd_stash = nullptr;
+    // what a successful vit_forward_train wrote into a caller's stash, by stash address: every backward stage on that
+    // stash must be called with the same batch (the stash layout is derived from it) and, for the embedding stage, the
+    // same pixel dtype. Several stashes may be in flight (micro-batches, gradient accumulation); the table is bounded.
+    struct Filled { int batch, pixel_dtype; };
+    std::map<const void*, Filled> filled;
+    static constexpr size_t kMaxFilled = 256;
 };
 
 int launch_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* db, float* slabs, int T, int Mo, int No,
@@ -377,13 +379,19 @@ extern "C" int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel
         return VIT_OK;
     };
 
-    ctx->train->fwd_batch = batch;
-    ctx->train->fwd_pixel_dtype = pixel_dtype;
-    ctx->train->fwd_stash = stash_;
+    // the stash counts as filled only once every launch of this call has been enqueued without an error
+    ctx->train->filled.erase(stash_);
+    auto mark_filled = [&](int rc) {
+        if (rc == VIT_OK) {
+            if (ctx->train->filled.size() >= TrainState::kMaxFilled) ctx->train->filled.clear();
+            ctx->train->filled[stash_] = TrainState::Filled{batch, pixel_dtype};
+        }
+        return rc;
+    };
     // as vit_forward: two chunks on two streams, so one chunk's kernels fill the CUs the other's last
     // round of GEMM tiles leaves idle (the stash keeps its single-batch layout)
     const int k = vit_num_chunks(ctx, batch) >= 2 ? 2 : 1;
-    if (k == 1) return run(0, batch, stream);
+    if (k == 1) return mark_filled(run(0, batch, stream));
     const int h0 = vit_chunk_begin(batch, 2, 1);
     VIT_CHECK_HIP(hipEventRecord(ctx->ev_fork, stream));
     VIT_CHECK_HIP(hipStreamWaitEvent(ctx->aux_stream[0], ctx->ev_fork, 0));
@@ -393,7 +401,7 @@ extern "C" int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel
     hipError_t e = hipEventRecord(ctx->ev_join[0], ctx->aux_stream[0]);
     if (e == hipSuccess) e = hipStreamWaitEvent(stream, ctx->ev_join[0], 0);
     if (e != hipSuccess && rc == VIT_OK) rc = vit_set_error(VIT_E_HIP, "vit_forward_train: stream join: %s", hipGetErrorString(e));
-    return rc;
+    return mark_filled(rc);
 }
 
 // ---------------------------------------------------------------- backward, in stages
@@ -406,9 +414,11 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
     VIT_REQUIRE(ctx->train, "vit_backward_stage: call vit_train_init first");
     VIT_REQUIRE(stash_ && grads_ && workspace, "vit_backward_stage: null argument");
     VIT_REQUIRE(batch > 0, "vit_backward_stage: batch must be positive (got %d)", batch);
-    VIT_REQUIRE(ctx->train->fwd_batch == batch && ctx->train->fwd_stash == stash_,
-                "vit_backward_stage: batch %d / stash %p do not match the last vit_forward_train (batch %d, stash %p)", batch,
-                stash_, ctx->train->fwd_batch, ctx->train->fwd_stash);
+    const auto filled = ctx->train->filled.find(stash_);
+    VIT_REQUIRE(filled != ctx->train->filled.end(), "vit_backward_stage: stash %p was not filled by a vit_forward_train of this context",
+                stash_);
+    VIT_REQUIRE(filled->second.batch == batch, "vit_backward_stage: batch %d does not match the vit_forward_train that filled stash %p (batch %d)",
+                batch, stash_, filled->second.batch);
     const TGeo g = tgeo(ctx, batch);
     VIT_REQUIRE(stage >= 0 && stage <= g.L + 1, "vit_backward_stage: stage %d outside [0, %d]", stage, g.L + 1);
     const Stash st = plan_stash(ctx, batch);
@@ -509,8 +519,8 @@ extern "C" int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_de
 
     // ---- embeddings (modeling_vit.py:129-161, 62-69; modeling_clip.py:202-218, 642)
     VIT_REQUIRE(pixels_dev != nullptr, "vit_backward_stage: the embedding stage needs the pixels");
-    VIT_REQUIRE(pixel_dtype == ctx->train->fwd_pixel_dtype, "vit_backward_stage: pixel dtype %d differs from vit_forward_train's %d",
-                pixel_dtype, ctx->train->fwd_pixel_dtype);
+    VIT_REQUIRE(pixel_dtype == filled->second.pixel_dtype, "vit_backward_stage: pixel dtype %d differs from vit_forward_train's %d",
+                pixel_dtype, filled->second.pixel_dtype);
     const void* dxe = dx;
     if (clip) {
         VIT_TRY(launch_layernorm_bwd(S + st.xe, dx, ctx->pre_g, nullptr, dx2, G + ctx->g_pre_g, G + ctx->g_pre_b, g.M, g.D,

@@ -123,10 +123,28 @@ class ViTEncoder:
                     raise KeyError(f"1 tensors missing from state_dict, e.g. {k!r}")
 
     def weights_changed(self) -> None:
-        """Drop the per-resolution clones made by ``with_image_size`` (each holds a device copy of the weights as
-        they were when it was made). Called by ``load_state_dict`` and by ``ViTTrainer.sgd_step``."""
-        for e in self.__dict__.pop("_resized", {}).values():
-            e.close()
+        """Mark the per-resolution clones made by ``with_image_size`` stale (each holds a device copy of the weights
+        as they were when it was made). A stale clone stays a valid object: its next ``forward`` re-clones from this
+        encoder (weights copied device to device, position table re-interpolated). Called by ``load_state_dict`` and
+        by ``ViTTrainer.sgd_step``; costs nothing until a clone is used again."""
+        for e in self.__dict__.get("_resized", {}).values():
+            e._stale = True
+
+    def _refresh_clone(self) -> None:
+        parent = self._parent
+        if parent._ctx is None:
+            raise RuntimeError("this resized encoder's parent has been closed")
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            if self._ctx is not None and self._ctx:
+                torch.cuda.synchronize(self.device)
+                _lib.load().vit_destroy(self._ctx)
+                self._ctx = None
+            _lib.check(_lib.load().vit_clone_resized(parent._ctx, self.config.image_size, ctypes.byref(handle),
+                                                     torch.cuda.current_stream().cuda_stream))
+        self._ctx = handle
+        self._head = parent._head
+        self._stale = False
 
     def _head_keys(self) -> dict:
         d = self.config.hidden_size
@@ -169,16 +187,18 @@ class ViTEncoder:
             new.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_ctx", "_ws", "_resized", "config")})
             new.config = dataclasses.replace(self.config, image_size=image_size)
             new._ws = None
-            handle = ctypes.c_void_p()
-            with torch.cuda.device(self.device):
-                _lib.check(_lib.load().vit_clone_resized(self._ctx, image_size, ctypes.byref(handle),
-                                                         torch.cuda.current_stream().cuda_stream))
-            new._ctx = handle
+            new._ctx = None
+            new._parent = self
+            new._refresh_clone()
             cache[image_size] = new
         return cache[image_size]
 
     def forward(self, pixel_values: torch.Tensor, interpolate_pos_encoding: bool = False) -> EncoderOutput:
         cfg = self.config
+        if getattr(self, "_stale", False):
+            self._refresh_clone()
+        if self._ctx is None:
+            raise RuntimeError("this ViTEncoder has been closed")
         if pixel_values.dim() != 4:
             raise ValueError("pixel_values must be [batch, channels, height, width]")
         b, c, h, w = pixel_values.shape

@@ -125,7 +125,7 @@ class ViTTrainer:
 
 class DataParallelTrainer:
     """Batch-sharded DP training: every rank runs the local step; the gradients of a backward
-    stage are all-reduced (sum, then scaled by 1/world) on a side stream as soon as that stage
+    stage are all-reduced (averaged) on a side stream as soon as that stage
     is enqueued, overlapping RCCL over xGMI with the next layer's backward. One bucket per
     transformer layer (contiguous by construction) plus one for embeddings / norms."""
 
@@ -136,10 +136,15 @@ class DataParallelTrainer:
         self.group = group
         self.world = dist.get_world_size(group)
         self.comm = torch.cuda.Stream(device=trainer.device) if trainer.device.type == "cuda" else None
+        # RCCL averages inside the collective; gloo (the CPU tests) has no AVG and scales in a second pass
+        self._avg = dist.get_backend(group) == "nccl"
 
     def _reduce(self, view: torch.Tensor):
-        self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group)
-        view.mul_(1.0 / self.world)
+        if self._avg:
+            self.dist.all_reduce(view, op=self.dist.ReduceOp.AVG, group=self.group)
+        else:
+            self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group)
+            view.mul_(1.0 / self.world)
 
     def backward(self, d_hidden=None, d_pooled=None):
         t = self.t
