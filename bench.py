@@ -269,7 +269,9 @@ CONFIGS = {
     #       [weak: images per GPU; strong: global images])
     "b16": (ViTConfig.vit_b16_224, "ViT-B/16 224^2", "configs[1]", "weak", 256),
     "l14": (ViTConfig.clip_l14_336, "ViT-L/14 336^2 (CLIP vision tower)", "configs[2]", "strong", 128),
-    "h14": (ViTConfig.vit_h14_448, "ViT-H/14 448^2", "configs[3]", "weak", 32),
+    # h14: batch per GPU "chosen to fill" (SURVEY.md 8d): swept 32 / 48 / 64 / 96 on one MI355X (round 3, one box):
+    # 771.9 / 777.3 / 783.2 / 783.0 images/s -- 64 images = 65,600 token rows is where the per-image rate levels off
+    "h14": (ViTConfig.vit_h14_448, "ViT-H/14 448^2", "configs[3]", "weak", 64),
 }
 
 

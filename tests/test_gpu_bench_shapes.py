@@ -22,9 +22,9 @@ DEV = "cuda:0"
 BF16_TOL = 1.0 / 128
 SHAPES = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]  # (N, K): q/k/v, o_proj, fc1, fc2 of ViT-B/16
 MS = [50432, 50431]
-# configs[2] / [3] at the batch they are benched at: CLIP-L/14-336 batch 128 (M = 128 * 577) and ViT-H/14-448 batch 32
-# (M = 32 * 1025), each with a ragged M as well; (M, N, K) for q/k/v, o_proj, fc1, fc2
-L14_M, H14_M = 128 * 577, 32 * 1025
+# configs[2] / [3] at the batch they are benched at: CLIP-L/14-336 batch 128 (M = 128 * 577) and ViT-H/14-448 batch 64
+# (M = 64 * 1025), each with a ragged M as well; (M, N, K) for q/k/v, o_proj, fc1, fc2
+L14_M, H14_M = 128 * 577, 64 * 1025
 BIG = [(m, n, k) for m in (L14_M, L14_M - 1) for (n, k) in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096))] + \
       [(m, n, k) for m in (H14_M, H14_M - 1) for (n, k) in ((3840, 1280), (1280, 1280), (5120, 1280), (1280, 5120))]
 ALL_MNK = [(m, n, k) for (n, k) in SHAPES for m in MS] + BIG

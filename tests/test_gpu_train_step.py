@@ -163,7 +163,7 @@ def test_two_stashes_in_flight_and_unknown_stash_rejected():
     enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=DEV)
     enc.load_state_dict(sd)
     tr = ViTTrainer(enc)
-    key = ("layers.1.mlp.fc1.weight", "layers.0.attention.q_proj.weight", "layers.1.attention.o_proj.weight")
+    key = ("layers.0.mlp.fc1.weight", "layers.0.attention.q_proj.weight", "layers.0.attention.o_proj.weight")
     want = []
     for p in px:
         tr.forward(p)
