@@ -3,6 +3,7 @@ small script in a child process (the child is started BEFORE it touches the GPU;
 
 * VIT_AMD_GEMM_GC: the column-grouped tile order of the persistent GEMM only changes WHICH workgroup computes a tile
   and when -- the output must be bit-identical to the plain mt-major order, for every epilogue that kernel has.
+* VIT_AMD_GEMM_MI: tile height of the persistent GEMM (few-tile planner of gemm_bf16_8p.hip): same bits at every height.
 * VIT_AMD_ATTN_RING: head_dim-80 attention on the LDS-DMA ring kernel against the staged kernel it replaces (both
   fp32 online softmax over 32-key tiles; checked to bf16 tolerance, and both against the oracle in test_gpu_kernels).
 * VIT_AMD_SPLIT_PCT / VIT_AMD_STREAMS: where vit_forward cuts the batch for its two streams changes which launch a row
@@ -54,6 +55,33 @@ print(json.dumps({"ok": all(bool(torch.isfinite(o.float()).all()) for o in outs.
 """
 
 
+FEWTILE_SCRIPT = r"""
+import hashlib, json, sys, torch
+from vit_amd import ops, synth
+dev = "cuda:0"
+out = {}
+h = lambda t: hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
+# few-tile shapes (M < 12608 rows): the planner picks 192-row tiles (M = 9232, N = 1024: 196 tiles in one round), a
+# head of 256-row tiles plus a shorter tail, or 128-row tiles, by shape; ragged M and N
+for (m, n, k) in [(9232, 1024, 1024), (9232, 3072, 1024), (6304, 768, 2048), (4616, 4096, 1024), (5001, 1000, 256)]:
+    x = (synth.normal((m, k), 3, "x") * 1.5 + 0.3).to(dev, torch.bfloat16)
+    w = synth.normal((n, k), 4, "w", std=0.05).to(dev, torch.bfloat16)
+    b = synth.normal((n,), 5, "b", std=0.1).to(dev)
+    r = synth.normal((m, n), 6, "r").to(dev, torch.bfloat16)
+    g, be = synth.normal((k,), 7, "g", 0.1, 1.0).to(dev), synth.normal((k,), 7, "be", 0.1).to(dev)
+    st = ops.layer_norm_stats(x, 1e-5)
+    fold = ops.layer_norm_fold(w, g, be, b)
+    for epi in (None, "gelu", "quick_gelu"):
+        out[f"{m}x{n}x{k}:lnf:{epi}"] = h(ops.linear_ln_folded(x, fold, st, epi))
+    out[f"{m}x{n}x{k}:res"] = h(ops.linear(x, w, b, residual=r))
+    inplace = r.clone()   # the encoder's call: C aliases the residual
+    from vit_amd import _lib
+    _lib.check(_lib.load().vit_gemm_bias_act(x.data_ptr(), w.data_ptr(), b.data_ptr(), inplace.data_ptr(), inplace.data_ptr(), m, n, k,
+                                             _lib.EPI_RESIDUAL, _lib.VIT_BF16, torch.cuda.current_stream().cuda_stream))
+    out[f"{m}x{n}x{k}:res_inplace"] = h(inplace)
+print(json.dumps(out))
+"""
+
 SPLIT_SCRIPT = r"""
 import hashlib, json, torch
 from vit_amd import synth
@@ -87,6 +115,19 @@ def test_grouped_tile_order_gives_the_same_bits_as_plain_order():
     assert plain.keys() == grouped.keys() and len(plain) == 8
     assert plain == grouped
     assert plain == narrow
+
+
+def test_few_tile_planner_gives_the_same_bits_as_256_row_tiles():
+    """VIT_AMD_GEMM_MI: 4 = 256-row tiles only, 3 / 2 = 192- / 128-row tiles everywhere, unset = the planner (tile height
+    and head / tail cut by shape). The k order of an output element is the same in all of them: bit-identical outputs."""
+    ref = run_child(FEWTILE_SCRIPT, {"VIT_AMD_GEMM_MI": "4"})
+    assert len(ref) == 25
+    for mi in ("3", "2"):
+        assert run_child(FEWTILE_SCRIPT, {"VIT_AMD_GEMM_MI": mi}) == ref, mi
+    assert run_child(FEWTILE_SCRIPT, {}) == ref
+    for k in ref:
+        if k.endswith(":res"):
+            assert ref[k] == ref[k + "_inplace"], k
 
 
 def test_ring_attention_matches_staged_kernel(tmp_path):

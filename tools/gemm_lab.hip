@@ -2,10 +2,12 @@
 // against the shipped kernel on the ViT-B/16 batch-256 shapes, random bf16 operands,
 // interleaved rounds in one process (cdna_hip_programming.md rule 24).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/gemm_lab.hip -o tools/gemm_lab
-#define G8_LAB 1
+// (the in-kernel stamps and the no-store timing build of rounds 1-2 -- G8_LAB in gemm_bf16_8p.hip -- were removed from the
+// shipped kernel in round 3; they are in the history at commit f9e38f8)
 #include <type_traits>
 #include "../vit_amd/csrc/gemm_bf16.hip"
 #include "../vit_amd/csrc/gemm_bf16_8p.hip"
+#define G8_LAB 1  // the lab hooks of the lab-only 4-wave kernel (nothing in vit_amd/csrc reads it)
 #include "gemm4w_lab.hip"
 #include <stdarg.h>
 #include <stdio.h>
@@ -218,7 +220,6 @@ int main(int argc, char** argv) {
             vars.push_back({"lnf8p", [&](bf16_t* C) {
                 GemmExt e{}; e.ln_stats = lnst; e.ln_colsum = lnc;
                 launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, &e, st); }});
-        vars.push_back({"ns8p", [&](bf16_t* C) { g8_dbg = 1; launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); g8_dbg = 0; }});
         vars.push_back({"ring<2,2,3>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<2, 2, 3, VIT_EPI_GELU>(Q, st) : lab::launch_ring<2, 2, 3, VIT_EPI_BIAS>(Q, st); }});
         vars.push_back({"ring<1,4,3>", [&](bf16_t* C) { GemmParams Q = P; Q.C = C; gelu ? lab::launch_ring<1, 4, 3, VIT_EPI_GELU>(Q, st) : lab::launch_ring<1, 4, 3, VIT_EPI_BIAS>(Q, st); }});
         if (*var_f) { std::vector<Var> keep; for (auto& v : vars) if (!strcmp(v.name, "shipped") || strstr(var_f, v.name)) keep.push_back(v); vars = keep; }
@@ -252,27 +253,6 @@ int main(int argc, char** argv) {
             std::sort(ms[v].begin(), ms[v].end());
             printf("%-9s %-12s median %8.1f us  %7.1f TF   (min %8.1f us)\n", sh.name, vars[v].name, ms[v][rounds / 2] * 1e3,
                    flop / (ms[v][rounds / 2] * 1e-3) / 1e12, ms[v][0] * 1e3);
-        }
-        {   // per-workgroup stamps around the second tile (G8_STAMP in the kernel), 100 MHz counter
-            unsigned long long* ds; hipMalloc(&ds, 256 * 8 * 8); hipMemset(ds, 0, 256 * 8 * 8);
-            g8_stamps = ds;
-            GemmExt se{}; se.ln_stats = lnst; se.ln_colsum = lnc;  // LAB_LNF_STAMPS=1: stamp the folded-LayerNorm variant
-            const bool lnf_st = getenv("LAB_LNF_STAMPS") && (sh.epi == VIT_EPI_BIAS || sh.epi == VIT_EPI_GELU);
-            for (int w = 0; w < 3; ++w) launch_gemm_bf16_8p(A, W, B, R, C1, sh.M, sh.N, sh.K, sh.epi, lnf_st ? &se : nullptr, st);
-            hipStreamSynchronize(st);
-            g8_stamps = nullptr;
-            std::vector<unsigned long long> hs(256 * 8);
-            hipMemcpy(hs.data(), ds, 256 * 8 * 8, hipMemcpyDeviceToHost);
-            double d[5] = {0, 0, 0, 0, 0}; int n = 0;
-            for (int b = 0; b < 256; ++b) {
-                const unsigned long long* q = &hs[b * 8];
-                if (!q[0] || !q[5]) continue;
-                d[0] += (q[1] - q[0]) / 100.0; d[1] += (q[2] - q[1]) / 100.0; d[2] += (q[3] - q[2]) / 100.0;
-                d[3] += (q[4] - q[3]) / 100.0; d[4] += (q[5] - q[4]) / 100.0; ++n;
-            }
-            if (n) printf("%-9s stamps (%d wgs): main loop %.2f us (%d K-tiles), wait vm(4) %.2f, epilogue %.2f, next tile K-tile0 %.2f, K-tile1 %.2f\n",
-                          sh.name, n, d[0] / n, sh.K / 64, d[1] / n, d[2] / n, d[3] / n, d[4] / n);
-            hipFree(ds);
         }
         hipFree(A); hipFree(W); hipFree(C0); hipFree(C1); hipFree(B); hipFree(R);
         fflush(stdout);

@@ -71,29 +71,21 @@ __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned l
 }
 
 // Folded LayerNorm: read n of the epilogue brings two rows' (mean * rstd, rstd) of the lane's rows
-// (ha = n >> 3, mi = (n >> 1) & 3, row pair n & 1) into slot n % 3 of a three-deep window.
-template <int N>
+// (ha = n / (2 MI), mi = (n >> 1) % MI, row pair n & 1; an A half has 32 MI rows) into slot n % 3 of a three-deep window.
+template <int N, int MI>
 __device__ __forceinline__ void st_read(f32x4 (&spw)[3], unsigned st_lds) {
-    constexpr int off = ((N >> 3) * 128 + ((N >> 1) & 3) * 16 + (N & 1) * 2) * 8;
+    static_assert(N < 4 * MI, "statistics read past the tile");
+    constexpr int off = ((N / (2 * MI)) * 32 * MI + ((N >> 1) % MI) * 16 + (N & 1) * 2) * 8;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(spw[N % 3]) : "v"(st_lds), "n"(off) : "memory");
 }
+template <int MI>
 __device__ __forceinline__ void st_read_sw(int n, f32x4 (&spw)[3], unsigned st_lds) {  // n is a constant after unrolling
+#define G8_ST_CASE(K) case K: if constexpr (K < 4 * MI) st_read<K, MI>(spw, st_lds); break
     switch (n) {
-        case 2: st_read<2>(spw, st_lds); break;
-        case 3: st_read<3>(spw, st_lds); break;
-        case 4: st_read<4>(spw, st_lds); break;
-        case 5: st_read<5>(spw, st_lds); break;
-        case 6: st_read<6>(spw, st_lds); break;
-        case 7: st_read<7>(spw, st_lds); break;
-        case 8: st_read<8>(spw, st_lds); break;
-        case 9: st_read<9>(spw, st_lds); break;
-        case 10: st_read<10>(spw, st_lds); break;
-        case 11: st_read<11>(spw, st_lds); break;
-        case 12: st_read<12>(spw, st_lds); break;
-        case 13: st_read<13>(spw, st_lds); break;
-        case 14: st_read<14>(spw, st_lds); break;
-        case 15: st_read<15>(spw, st_lds); break;
+        G8_ST_CASE(2); G8_ST_CASE(3); G8_ST_CASE(4); G8_ST_CASE(5); G8_ST_CASE(6); G8_ST_CASE(7); G8_ST_CASE(8);
+        G8_ST_CASE(9); G8_ST_CASE(10); G8_ST_CASE(11); G8_ST_CASE(12); G8_ST_CASE(13); G8_ST_CASE(14); G8_ST_CASE(15);
     }
+#undef G8_ST_CASE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -111,8 +103,8 @@ struct PParams {
     int M, N, K;     // K = reduction length of ONE split
     int lda;         // row pitch (elements) of A and W: K * splits
     int NT;      // tiles along N
-    int MT, GC;  // tiles along M; column-group width of the tile order (see tile_coords)
-    int TMN;     // output tiles per split = ceil(M/256) * NT
+    int MT, GC;  // tiles along M (of 64 MI rows each); column-group width of the tile order (see tile_coords)
+    int TMN;     // output tiles per split = MT * NT
     int T;       // total work items = TMN * splits; split s writes the fp32 slab C + s*M*N (OUTM 1)
     // LNF (template flag): LayerNorm folded in -- epilogue value = rstd * acc - (mean * rstd) * ln_c + bias
     const float* ln_stats;   // [M][2] = (mean * rstd, rstd)
@@ -123,8 +115,6 @@ struct PParams {
     unsigned img_bytes;      // C * image * image * 2
     int a_kshift, a_kmask;   // K-tile kt starts at byte (kt >> a_kshift) * a_chs + (kt & a_kmask) * a_kts of a patch
     unsigned a_chs, a_kts;
-    int dbg;     // lab only (G8_LAB): bit0 = timing-only run without output stores
-    unsigned long long* stamps;  // lab only: 8 x s_memrealtime per workgroup around its second tile
 };
 
 constexpr int EPI_PATCH = 100;        // internal: bias + position add + row remap past the CLS slot, A from pixels
@@ -133,9 +123,20 @@ constexpr int EPI_PATCH_DENSE = 101;  // the same epilogue on a dense A (rows = 
 // EPI: VIT_EPI_* or EPI_PATCH; for VIT_EPI_DGELU / VIT_EPI_DQUICK_GELU `res` is the pre-activation the
 // gradient is multiplied with. OUTM: 0 = bf16 C, 1 = fp32 C (weight gradients), 2 = bf16 C plus
 // the pre-activation in Cpre.
-template <int EPI, int OUTM, bool LNF = false>
+// MI: 16-row MFMA fragments per wave and A half -- the tile is 64 MI rows x 256 columns (MI = 4: 256 x 256, the shape
+// everything above describes). MI = 3 / 2 are the FEW-TILE forms for shapes whose 256-row tiles fill the chip badly
+// (CLIP-L/14 at 16 images: 148 tiles on 256 CUs; pick_mi below): an A half holds 32 MI rows in its first LDS rows (the
+// DMA lanes of the other rows are out of range and move nothing), a wave owns 16 MI of them, and a phase has 4 MI MFMAs.
+// Everything else -- schedule, waits, LDS image, k order -- is the same, so an output element gets the SAME BITS whatever
+// MI computed it: the tile height is a pure speed choice, like the tile order.
+template <int EPI, int OUTM, bool LNF = false, int MI = 4>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(MI >= 2 && MI <= 4, "tile height 128 / 192 / 256");
+    static_assert(MI == 4 || (EPI != EPI_PATCH && EPI != EPI_PATCH_DENSE), "the patch epilogues assume 256-row tiles");
+    constexpr int BMT = 64 * MI;  // tile rows
+    constexpr int HR = 32 * MI;   // rows of an A half
+    constexpr int WRR = 16 * MI;  // rows of a wave inside an A half
 
     // ---- tile list of this workgroup. Blocks b and b+8 share an XCD (label x = b % XL); label
     // x owns one contiguous chunk of the (mt-major) tile space and its blocks walk the chunk
@@ -174,14 +175,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         const int sp = tile_idx / P.TMN, t2 = tile_idx - sp * P.TMN;
         int mt, nt;
         tile_coords(t2, &mt, &nt);
-        const int m0 = mt * BM, n0 = nt * BN;
+        const int m0 = mt * BMT, n0 = nt * BN;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = j * 64 + (tid >> 3);
                 const int sw = (r >> 1) & 7;
-                int ar = h * 128 + r;
+                int ar = h * HR + r;
                 if (m0 + ar > P.M - 1) ar = P.M - 1 - m0;
                 if constexpr (EPI == EPI_PATCH) {
                     // patch row: offset of its first pixel from the tile's first image, plus this lane's
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                     a_of[h][j] = (unsigned)(b - m0 / P.np) * P.img_bytes + pix * 2u;
                 } else {
                     a_of[h][j] = ((unsigned)ar * (unsigned)P.lda + (unsigned)((p ^ sw) << 3)) * 2u;
+                    if (MI < 4 && r >= HR) a_of[h][j] = 0x80000000u;  // LDS rows the tile does not use: out of range, nothing moves
                 }
                 const int rr = r & 31;
                 // B half h, LDS row (wc*32 + ni*16 + c) holds tile column wc*64 + 4c + (2h + ni): the four
@@ -201,8 +203,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                 if (n0 + wrow > P.N - 1) wrow = P.N - 1 - n0;
                 w_of[h][j] = ((unsigned)wrow * (unsigned)P.lda + (unsigned)((p ^ sw) << 3)) * 2u;
             }
-        // num_records spans the (clamped) 256 rows of the tile; offsets never exceed it
-        const unsigned span = (unsigned)BM * (unsigned)P.lda * 2u;
+        // num_records spans the (clamped) rows of the tile; offsets never exceed it
+        const unsigned span = (unsigned)BN * (unsigned)P.lda * 2u;
+        const unsigned span_a = (unsigned)BMT * (unsigned)P.lda * 2u;
         const size_t koff = (size_t)sp * P.K;  // this split's first k
         if constexpr (EPI == EPI_PATCH) {
             // based at the tile's first image; the (clamped) rows of a tile lie in at most 256 / np + 2 images
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             Ar = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)P.A + (size_t)b0 * P.img_bytes), 0,
                                                    (unsigned)nimg * P.img_bytes, 0x00020000);
         } else {
-            Ar = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * P.lda + koff), 0, span, 0x00020000);
+            Ar = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * P.lda + koff), 0, span_a, 0x00020000);
         }
         Wr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * P.lda + koff), 0, span, 0x00020000);
     };
@@ -230,18 +233,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     };
 
     const int sw = i >> 1;
-    const unsigned rd_a = (unsigned)((wr * 64 + i) * 128);
+    const unsigned rd_a = (unsigned)((wr * WRR + i) * 128);
     const unsigned rd_b = (unsigned)((wc * 32 + i) * 128);
     const unsigned ck0 = (unsigned)((q ^ sw) << 4), ck1 = (unsigned)(((4 + q) ^ sw) << 4);
 
-    bf16x8 af[4][2];
+    bf16x8 af[MI][2];
     bf16x8 bfr[2][2][2];
-    f32x4 acc[2][4][2][2];
+    f32x4 acc[2][MI][2][2];
 
     auto read_a = [&](int buf, int h) {
         const unsigned char* b0 = smem + buf * BUF_BYTES + (h ? OFF_A1 : OFF_A0) + rd_a;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             af[mi][0] = *(const bf16x8*)(b0 + mi * 2048 + ck0);
             af[mi][1] = *(const bf16x8*)(b0 + mi * 2048 + ck1);
         }
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const f32x4 c = (ZERO && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[ha][mi][hb][ni];
@@ -341,13 +344,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // team 1 runs one barrier behind team 0
 
-#ifdef G8_LAB
-    unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int tcount = 0;
-#define G8_STAMP(i, cond) do { if (P.stamps && (cond)) stp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define G8_STAMP(i, cond) do { } while (0)
-#endif
     for (;;) {
         const int nlt = lt + gx;
         const bool has_next = nlt < cnt;
@@ -355,9 +351,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
         if constexpr (LNF || SIDE) {
             int mt, nt;
             tile_coords(cur_tile % P.TMN, &mt, &nt);
-            const int m0 = mt * BM, n0 = nt * BN;
+            const int m0 = mt * BMT, n0 = nt * BN;
             if constexpr (LNF) {
-                const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
+                const int rows_here = (P.M - m0 < BMT) ? P.M - m0 : BMT;
                 Sr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.ln_stats + (size_t)m0 * 2), 0, (unsigned)rows_here * 8u, 0x00020000);
             }
             if constexpr (SIDE) {
@@ -367,11 +363,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                 BLr = __builtin_amdgcn_make_buffer_rsrc((void*)(side ? side + n0 : P.ln_stats), 0, side ? (unsigned)cols_here * 4u : 0u, 0x00020000);
             }
         }
-        G8_STAMP(0, tcount == 1);
         ktile(I0{}, I0{}, BT{}, 0);
-        G8_STAMP(4, tcount == 2);
         ktile(I1{}, I0{}, BF{}, 1);
-        G8_STAMP(5, tcount == 2);
         for (int t = 2; t < nk - 2; t += 2) {
             ktile(I0{}, I0{}, BF{}, t);
             ktile(I1{}, I0{}, BF{}, t + 1);
@@ -381,10 +374,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
 
         // Both teams run the epilogue in the same barrier interval: team 0 waits one barrier
         // before it, team 1 one barrier after it (which also restores the stagger).
-        G8_STAMP(1, tcount == 1);
         if (wr == 0) __builtin_amdgcn_s_barrier();
         G8_WAIT_VM(4);  // retire B_h1/A_h1 of the next tile's K-tile 0 before any epilogue traffic
-        G8_STAMP(2, tcount == 1);
         {
             // lane (c = lane&15, g = lane>>4): acc[ha][mi][hb][ni][j] is output row
             // ha*128 + wr*64 + mi*16 + 4g + j, column wc*64 + 4c + (2hb + ni): 8-byte stores, 16 lanes
@@ -395,10 +386,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             const int sp = cur_tile / P.TMN, t2 = cur_tile - sp * P.TMN;
             int mt, nt;
             tile_coords(t2, &mt, &nt);
-            const int m0 = mt * BM, n0 = nt * BN;
+            const int m0 = mt * BMT, n0 = nt * BN;
             const int nb = n0 + wc * 64 + 4 * i;
             const bool col_ok = nb < P.N;  // N % 8 == 0: 4 columns all in or all out
-            const int rows_here = (P.M - m0 < BM) ? P.M - m0 : BM;
+            const int rows_here = (P.M - m0 < BMT) ? P.M - m0 : BMT;
             if constexpr (EPI == EPI_PATCH || EPI == EPI_PATCH_DENSE) {
                 // GEMM row g = b * np + patch goes to output row g + b + 1 (one CLS slot per image) and gets
                 // position row 1 + patch. The tile's rows lie in at most 5 images (np >= 64, host check):
@@ -407,7 +398,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                 const int e1 = (b0 + 1) * P.np - m0;
                 const unsigned out_rows = (unsigned)(rows_here + (m0 + rows_here - 1) / P.np - b0);
                 const __amdgpu_buffer_rsrc_t Cr = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*)(P.C + (size_t)(m0 + b0 + 1) * P.N), 0, (P.dbg & 1) ? 0u : out_rows * (unsigned)P.N * 2u, 0x00020000);
+                    (void*)(P.C + (size_t)(m0 + b0 + 1) * P.N), 0, out_rows * (unsigned)P.N * 2u, 0x00020000);
                 const __amdgpu_buffer_rsrc_t Qr = __builtin_amdgcn_make_buffer_rsrc(
                     (void*)P.pos, 0, (unsigned)(P.np + 1) * (unsigned)P.N * 4u, 0x00020000);
                 float bias[4] = {0.f, 0.f, 0.f, 0.f};
@@ -445,23 +436,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             } else {
             constexpr bool USES_RES = (EPI == VIT_EPI_RESIDUAL || EPI == VIT_EPI_DGELU || EPI == VIT_EPI_DQUICK_GELU);
             constexpr unsigned OES = (OUTM == 1) ? 4u : 2u;  // output element size
-            const unsigned span = (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * 2u;
+            const unsigned span = (unsigned)rows_here * (unsigned)P.N * 2u;
             const __amdgpu_buffer_rsrc_t Cr = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)((char*)P.C + ((size_t)sp * P.M + m0) * P.N * OES), 0, (P.dbg & 1) ? 0u : (unsigned)rows_here * (unsigned)P.N * OES,
+                (void*)((char*)P.C + ((size_t)sp * P.M + m0) * P.N * OES), 0, (unsigned)rows_here * (unsigned)P.N * OES,
                 0x00020000);
             __amdgpu_buffer_rsrc_t Rr = Cr, Pr = Cr;
             if constexpr (USES_RES)
                 Rr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.res + (size_t)m0 * P.N), 0, span, 0x00020000);
             if constexpr (OUTM == 2)
                 Pr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.Cpre + (size_t)m0 * P.N), 0, span, 0x00020000);
-            const unsigned voff0 = col_ok ? (unsigned)((wr * 64 + 4 * q) * P.N + nb) * 2u : 0x80000000u;
+            const unsigned voff0 = col_ok ? (unsigned)((wr * WRR + 4 * q) * P.N + nb) * 2u : 0x80000000u;
             // bias, ln_c (column sums of the folded weight) and the tile's (mean * rstd, rstd) are in LDS behind the ring
             // (DMA of the last K-tile), read by inline asm (a C++ LDS load behind an LDS-DMA draws a vmcnt(0)). The
             // statistics are read two rows at a time, two reads ahead of their use (all 32 rows' pairs up front held 64
             // more VGPRs through the epilogue and cost 7-8 us per launch; one read ahead left the LDS latency exposed
             // sixteen times per tile, 17 us per launch of fc1 + GELU).
             const unsigned side_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + (unsigned)(LDS_BYTES + 2048 + (wc * 64 + 4 * i) * 4);
-            const unsigned st_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + (unsigned)(LDS_BYTES + (wr * 64 + 4 * q) * 8);
+            const unsigned st_lds = (unsigned)(uintptr_t)LDS_PTR(smem) + (unsigned)(LDS_BYTES + (wr * WRR + 4 * q) * 8);
             f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f}, lnc4 = f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 spw[3];
             if constexpr (!SIDE) {
@@ -472,21 +463,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             if constexpr (!SIDE) {
             } else if constexpr (LNF) {
                 asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(lnc4) : "v"(side_lds) : "memory");
-                st_read<0>(spw, st_lds);
-                st_read<1>(spw, st_lds);
+                st_read<0, MI>(spw, st_lds);
+                st_read<1, MI>(spw, st_lds);
                 asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bias4), "+v"(lnc4)::"memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias4)::"memory");
             }
             const float bias[4] = {bias4[0], bias4[1], bias4[2], bias4[3]};
             const float lnc[4] = {lnc4[0], lnc4[1], lnc4[2], lnc4[3]};
-            // residual / aux tile: the first RW of the lane's 32 row loads are issued up front into the (now dead) fragment
+            // residual / aux tile: the first RW of the lane's 8 MI row loads are issued up front into the (now dead) fragment
             // registers, load s + RW when row s has been consumed. (All 32 up front: 64 registers, and the spills they
             // forced were reloaded behind a vmcnt(0) at the top of every epilogue.)
-            constexpr int RW = (EPI == VIT_EPI_RESIDUAL) ? 24 : 16;
-            u32x2 rres[32];
+            constexpr int NROW = 8 * MI;  // rows of a lane: (ha, mi, j)
+            constexpr int RW = ((EPI == VIT_EPI_RESIDUAL) ? 6 : 4) * MI;
+            u32x2 rres[NROW];
             auto res_load = [&](int s) {
-                const unsigned voff = voff0 + (unsigned)(((s >> 4) * 128 + ((s >> 2) & 3) * 16 + (s & 3)) * P.N) * 2u;
+                const unsigned voff = voff0 + (unsigned)(((s / (4 * MI)) * HR + ((s >> 2) % MI) * 16 + (s & 3)) * P.N) * 2u;
                 return __builtin_amdgcn_raw_buffer_load_b64(Rr, (int)voff, 0, 0);  // (an nt hint here costs 0.7 % per forward: the rows were just written by the previous kernel)
             };
             if constexpr (USES_RES) {
@@ -496,20 +488,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const unsigned voff = voff0 + (unsigned)((ha * 128 + mi * 16 + j) * P.N) * 2u;
+                        const unsigned voff = voff0 + (unsigned)((ha * HR + mi * 16 + j) * P.N) * 2u;
                         float v[4];
                         if constexpr (LNF) {
                             // two rows' (mean * rstd, rstd): read n, issued two reads ago
-                            const int n = ha * 8 + mi * 2 + (j >> 1);
+                            const int n = (ha * MI + mi) * 2 + (j >> 1);
                             if ((j & 1) == 0) {
-                                if (n + 2 < 16) {
+                                if (n + 2 < 4 * MI) {
                                     // (the index must be a constant expression: spelled out per value of n)
-                                    st_read_sw(n + 2, spw, st_lds);
+                                    st_read_sw<MI>(n + 2, spw, st_lds);
                                     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(spw[n % 3])::"memory");
-                                } else if (n + 2 == 16) {
+                                } else if (n + 2 == 4 * MI) {
                                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(spw[n % 3])::"memory");
                                 } else {
                                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(spw[n % 3])::"memory");
@@ -548,7 +540,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                             v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
                         }
                         if constexpr (USES_RES) {
-                            const bf16x4 r = __builtin_bit_cast(bf16x4, rres[ha * 16 + mi * 4 + j]);
+                            const bf16x4 r = __builtin_bit_cast(bf16x4, rres[(ha * MI + mi) * 4 + j]);
                             if constexpr (EPI == VIT_EPI_DGELU) {
                                 const f32x2 g0 = act_dgelu_pk(f32x2{(float)r[0], (float)r[1]}), g1 = act_dgelu_pk(f32x2{(float)r[2], (float)r[3]});
                                 v[0] *= g0.x; v[1] *= g0.y; v[2] *= g1.x; v[3] *= g1.y;
@@ -571,8 +563,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, G8_STORE_AUX);
                         }
                         if constexpr (USES_RES) {
-                            const int sn = ha * 16 + mi * 4 + j + RW;
-                            if (sn < 32) {
+                            const int sn = (ha * MI + mi) * 4 + j + RW;
+                            if (sn < NROW) {
                                 __builtin_amdgcn_sched_barrier(0);  // not hoisted: the window is what keeps the registers down
                                 rres[sn] = res_load(sn);
                                 __builtin_amdgcn_sched_barrier(0);
@@ -581,19 +573,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
                     }
             }  // !EPI_PATCH
         }
-        G8_STAMP(3, tcount == 1);
-#ifdef G8_LAB
-        ++tcount;
-#endif
         if (wr == 1) __builtin_amdgcn_s_barrier();
         if (!has_next) break;
         lt = nlt;
         cur_tile = next_tile;
     }
-#ifdef G8_LAB
-    if (P.stamps && threadIdx.x == 0)
-        for (int i2 = 0; i2 < 8; ++i2) P.stamps[(size_t)blockIdx.x * 8 + i2] = stp[i2];
-#endif
     G8_WAIT_VM(0);  // the dummy prefetch of the last tile must land before the LDS is released
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance team 1's extra barrier
 }
@@ -608,9 +592,9 @@ inline int group_cols(int NT, int K) {
     return (NT + groups - 1) / groups;
 }
 
-template <int EPI, int OUTM, bool LNF = false>
+template <int EPI, int OUTM, bool LNF = false, int MI = 4>
 int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
-    auto kern = gemm8p_persist_kernel<EPI, OUTM, LNF>;
+    auto kern = gemm8p_persist_kernel<EPI, OUTM, LNF, MI>;
     static PerDeviceInt attr_set;  // per instantiation and device
     std::atomic<int>* as = attr_set.slot();
     if (!as || !as->load(std::memory_order_relaxed)) {
@@ -620,6 +604,94 @@ int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
     const int G = P.T < ncu ? P.T : ncu;
     hipLaunchKernelGGL(kern, dim3(G), dim3(NTHREADS), LDS_BYTES + 4096, stream, P);
     VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+// ---- few-tile planner. A launch of T tiles on ncu CUs takes ceil(T / ncu) tile ROUNDS however few tiles the last
+// round has; a small batch (the per-GPU shard of a strong-scaled batch: CLIP-L/14-336 at 16 images is 148 / 444 / 592
+// tiles of 256 x 256 on 256 CUs) loses up to 40 % of a GEMM that way. The kernel exists in three tile heights (64 MI
+// rows, same bits), and a row range can be cut in two launches (rows are independent), so the plan is: either one launch
+// at the best height, or a head of whole rounds of 256-row tiles plus a tail at its own best height. Cost model in
+// microseconds, fitted to tools/time_fewtile.py on MI355X (round 3): a K-tile takes 0.36 + 0.22 MI (the load section of a
+// phase does not shrink with the tile), the epilogue 0.8 MI, a launch 4. A pure function of (M, N, K, CUs): a given
+// shape always takes the same route; the bits do not depend on the route anyway (tests/test_gpu_switches.py).
+struct RowPlan {
+    int nseg;
+    int rows[2], mi[2];
+};
+inline double tile_us(int mi, int nk) { return nk * (0.36 + 0.22 * mi) + 0.8 * mi; }
+inline double single_us(int M, int NT, int nk, int ncu, int mi) {
+    const long tiles = (long)ceil_div(M, 64 * mi) * NT;
+    return 4.0 + (double)((tiles + ncu - 1) / ncu) * tile_us(mi, nk);
+}
+// Problems of at least kFewTileMaxRows rows keep 256-row tiles: vit_forward runs them as two chunks on two streams, and
+// there the other stream's kernels fill the CUs a partial round leaves idle -- shorter tiles (less work per operand byte)
+// then cost more than they save (same box, planner on / off: ViT-B/16 batch 256 8.70 / 8.48 ms, CLIP-L/14 batch 128
+// 43.2 / 42.6, ViT-H/14 batch 64 82.4 / 80.9; single-stream sizes: CLIP-L/14 batch 16 6.43 / 6.81 ms, ViT-B/16 batch 32
+// 1.87 / 2.14, ViT-H/14 batch 8 12.06 / 12.27).
+constexpr int kFewTileMaxRows = 2 * 32 * 197;  // = 2 x the minimum chunk of vit_num_chunks (vit_capi.hip)
+inline RowPlan plan_rows(int M, int N, int K, int ncu, bool allow) {
+    // lab switch VIT_AMD_GEMM_MI: 4 = 256-row tiles only (the kernel of rounds 1-2), 3 / 2 = that height everywhere
+    static const int forced = getenv("VIT_AMD_GEMM_MI") ? atoi(getenv("VIT_AMD_GEMM_MI")) : 0;
+    RowPlan best{1, {M, 0}, {4, 0}};
+    if (forced >= 2 && forced <= 4) {
+        best.mi[0] = forced;
+        return best;
+    }
+    if (!allow || M >= kFewTileMaxRows) return best;
+    const int NT = ceil_div(N, BN), nk = K / BK;
+    double best_us = single_us(M, NT, nk, ncu, 4);
+    auto best_single = [&](int rows, int* mi_out) {
+        double b = single_us(rows, NT, nk, ncu, 4);
+        *mi_out = 4;
+        for (int mi = 3; mi >= 2; --mi) {
+            const double c = single_us(rows, NT, nk, ncu, mi);
+            if (c < b * 0.97) { b = c; *mi_out = mi; }
+        }
+        return b;
+    };
+    int mi1;
+    const double one = best_single(M, &mi1);
+    if (one < best_us) { best_us = one; best.mi[0] = mi1; }
+    // head: r whole rounds of 256-row tiles (as many tile rows as fit r * ncu tiles), tail: the rest
+    for (int r = 1; r <= 8; ++r) {
+        const int head_rows = (int)((long)r * ncu / NT) * BM;
+        if (head_rows <= 0) continue;
+        if (head_rows >= M) break;
+        int mit;
+        const double c = single_us(head_rows, NT, nk, ncu, 4) + best_single(M - head_rows, &mit);
+        if (c < best_us * 0.97) {
+            best_us = c;
+            best = RowPlan{2, {head_rows, M - head_rows}, {4, mit}};
+        }
+    }
+    return best;
+}
+
+// inference-forward epilogues exist in all three tile heights; everything else is 256-row only.
+// Runs the row plan: segment s covers rows [row0, row0 + rows) of A, C, the residual and the LayerNorm statistics.
+template <int EPI, bool LNF>
+int launch_persist_planned(const PParams& P0, int ncu, bool allow, hipStream_t stream) {
+    const RowPlan plan = plan_rows(P0.M, P0.N, P0.K, ncu, allow);
+    int row0 = 0;
+    for (int sgm = 0; sgm < plan.nseg; ++sgm) {
+        PParams P = P0;
+        const int mi = plan.mi[sgm];
+        P.M = plan.rows[sgm];
+        P.A = P0.A + (size_t)row0 * P0.lda;
+        P.C = P0.C + (size_t)row0 * P0.N;
+        if (P0.res) P.res = P0.res + (size_t)row0 * P0.N;
+        if (P0.ln_stats) P.ln_stats = P0.ln_stats + (size_t)row0 * 2;
+        P.MT = ceil_div(P.M, 64 * mi);
+        P.TMN = P.MT * P.NT;
+        P.T = P.TMN;
+        int rc;
+        if (mi == 3) rc = launch_persist<EPI, 0, LNF, 3>(P, ncu, stream);
+        else if (mi == 2) rc = launch_persist<EPI, 0, LNF, 2>(P, ncu, stream);
+        else rc = launch_persist<EPI, 0, LNF, 4>(P, ncu, stream);
+        if (rc != VIT_OK) return rc;
+        row0 += plan.rows[sgm];
+    }
     return VIT_OK;
 }
 
@@ -641,10 +713,6 @@ bool gemm_bf16_8p_patch_eligible(int M, int N, const PatchGeom* g) {
            (size_t)g->channels * g->image * g->image * 2 * 7 < ((size_t)1 << 32) && (size_t)(g->grid * g->grid + 1) * N * 4 < ((size_t)1 << 32);
 }
 
-#ifdef G8_LAB
-int g8_dbg = 0;      // lab: bit0 = timing-only build without output stores
-unsigned long long* g8_stamps = nullptr;  // lab: device buffer of 8 stamps per workgroup
-#endif
 int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N, int K,
                         int epi, const GemmExt* ext, hipStream_t stream) {
     VIT_REQUIRE(gemm_bf16_8p_eligible(M, N, K), "gemm8p: shape M=%d N=%d K=%d not eligible", M, N, K);
@@ -663,12 +731,9 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
     P.TMN = P.MT * P.NT;
     P.T = P.TMN * splits;
     if (splits > 1) P.C = (bf16_t*)ext->slabs;
-#ifdef G8_LAB
-    P.dbg = g8_dbg;
-    P.stamps = g8_stamps;
-#endif
     const bool f32out = ext && ext->out_f32;
     const bool pre = P.Cpre != nullptr;
+    const bool few_ok = !(ext && ext->concurrent);
     VIT_REQUIRE(!(f32out && (epi != VIT_EPI_BIAS || pre)), "gemm8p: fp32 output only with the plain epilogue");
     VIT_REQUIRE(!pre || epi == VIT_EPI_GELU || epi == VIT_EPI_QUICK_GELU, "gemm8p: pre-activation output needs an activation epilogue");
     VIT_REQUIRE((size_t)256 * N * (f32out ? 4 : 2) < ((size_t)1 << 31), "gemm8p: N too large");
@@ -676,9 +741,9 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
         VIT_REQUIRE(ext->ln_colsum != nullptr && !f32out && !pre && splits == 1, "gemm8p: folded LayerNorm takes the plain bf16 epilogues only");
         P.ln_stats = ext->ln_stats; P.ln_c = ext->ln_colsum;
         switch (epi) {
-            case VIT_EPI_BIAS: return g8::launch_persist<VIT_EPI_BIAS, 0, true>(P, ncu, stream);
-            case VIT_EPI_GELU: return g8::launch_persist<VIT_EPI_GELU, 0, true>(P, ncu, stream);
-            case VIT_EPI_QUICK_GELU: return g8::launch_persist<VIT_EPI_QUICK_GELU, 0, true>(P, ncu, stream);
+            case VIT_EPI_BIAS: return g8::launch_persist_planned<VIT_EPI_BIAS, true>(P, ncu, few_ok, stream);
+            case VIT_EPI_GELU: return g8::launch_persist_planned<VIT_EPI_GELU, true>(P, ncu, few_ok, stream);
+            case VIT_EPI_QUICK_GELU: return g8::launch_persist_planned<VIT_EPI_QUICK_GELU, true>(P, ncu, few_ok, stream);
         }
         return vit_set_error(VIT_E_INVALID, "gemm8p: folded LayerNorm with epilogue %d", epi);
     }
@@ -691,7 +756,7 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
         case VIT_EPI_BIAS: return g8::launch_persist<VIT_EPI_BIAS, 0>(P, ncu, stream);
         case VIT_EPI_GELU: return pre ? g8::launch_persist<VIT_EPI_GELU, 2>(P, ncu, stream) : g8::launch_persist<VIT_EPI_GELU, 0>(P, ncu, stream);
         case VIT_EPI_QUICK_GELU: return pre ? g8::launch_persist<VIT_EPI_QUICK_GELU, 2>(P, ncu, stream) : g8::launch_persist<VIT_EPI_QUICK_GELU, 0>(P, ncu, stream);
-        case VIT_EPI_RESIDUAL: return g8::launch_persist<VIT_EPI_RESIDUAL, 0>(P, ncu, stream);
+        case VIT_EPI_RESIDUAL: return g8::launch_persist_planned<VIT_EPI_RESIDUAL, false>(P, ncu, few_ok, stream);
         case VIT_EPI_DGELU: return g8::launch_persist<VIT_EPI_DGELU, 0>(P, ncu, stream);
         case VIT_EPI_DQUICK_GELU: return g8::launch_persist<VIT_EPI_DQUICK_GELU, 0>(P, ncu, stream);
     }
@@ -722,10 +787,6 @@ int launch_gemm_bf16_8p_patch(const void* pixels, const void* W, const float* bi
     q.a_kshift = sh; q.a_kmask = kpc - 1;
     q.a_chs = (unsigned)g->image * g->image * 2u;          // next channel
     q.a_kts = (unsigned)(64 / P) * g->image * 2u;          // next 64 / P pixel rows
-#ifdef G8_LAB
-    q.dbg = g8_dbg;
-    q.stamps = g8_stamps;
-#endif
     return g8::launch_persist<g8::EPI_PATCH, 0>(q, ncu, stream);
 }
 
@@ -749,9 +810,5 @@ int launch_gemm_bf16_8p_patch_dense(const void* A, const void* W, const float* b
     q.TMN = q.MT * q.NT;
     q.T = q.TMN;
     q.np = g->grid * g->grid; q.grid = g->grid; q.patch = g->patch; q.image = g->image;
-#ifdef G8_LAB
-    q.dbg = g8_dbg;
-    q.stamps = g8_stamps;
-#endif
     return g8::launch_persist<g8::EPI_PATCH_DENSE, 0>(q, ncu, stream);
 }

@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // read once and nothing but 8 bytes per row is written.
 // Half a wave per row, 16-byte loads (8 bf16 per lane and step, NIT = ceil(dim / 256) steps), R row pairs per
 // wave in flight: a read-only pass wants wide loads and many bytes in flight.
-template <int NIT>
+// R row pairs per wave: 4 for big inputs (bytes in flight), 1 below ~20k rows, where 4 leaves one block per CU and the
+// launch is latency-bound (CLIP-L/14 at 16 images: 7.1 -> see DESIGN); a row's arithmetic does not depend on R.
+template <int NIT, int R>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const bf16_t* __restrict__ x, float2* __restrict__ stats, int rows,
                                                        int dim, int64_t xs, float eps) {
-    constexpr int R = 4;  // row pairs per wave
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const float inv_d = 1.0f / (float)dim;
@@ -310,11 +311,15 @@ int launch_layernorm(const void* x, const float* g, const float* b, void* y, int
 int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, float eps, int dtype, hipStream_t stream) {
     VIT_REQUIRE(rows > 0 && dim > 0 && dim % 8 == 0 && xs % 8 == 0 && dim <= 2048, "ln_stats: bad shape rows=%d dim=%d (multiples of 8)", rows, dim);
     VIT_REQUIRE(dtype == VIT_BF16, "ln_stats: bf16 only");
-    const int blocks = ceil_div(rows, 32);  // 4 waves x 4 row pairs, one step per wave
+    const bool small = rows < 20000;
+    const int blocks = ceil_div(rows, small ? 8 : 32);  // 4 waves x R row pairs, one step per wave
     const bf16_t* xp = (const bf16_t*)x;
     float2* sp = (float2*)stats;
-#define VIT_LN_STATS_CASE(NIT) \
-    case NIT: hipLaunchKernelGGL((ln_stats_kernel<NIT>), dim3(blocks), dim3(256), 0, stream, xp, sp, rows, dim, xs, eps); break;
+#define VIT_LN_STATS_CASE(NIT)                                                                                                   \
+    case NIT:                                                                                                                    \
+        if (small) hipLaunchKernelGGL((ln_stats_kernel<NIT, 1>), dim3(blocks), dim3(256), 0, stream, xp, sp, rows, dim, xs, eps); \
+        else hipLaunchKernelGGL((ln_stats_kernel<NIT, 4>), dim3(blocks), dim3(256), 0, stream, xp, sp, rows, dim, xs, eps);       \
+        break;
     switch (ceil_div(dim, 256)) {
         VIT_LN_STATS_CASE(1) VIT_LN_STATS_CASE(2) VIT_LN_STATS_CASE(3) VIT_LN_STATS_CASE(4)
         VIT_LN_STATS_CASE(5) VIT_LN_STATS_CASE(6) VIT_LN_STATS_CASE(7) VIT_LN_STATS_CASE(8)

@@ -429,7 +429,7 @@ extern "C" size_t vit_workspace_bytes(const vit_ctx* ctx, int batch) {
     } while (0)
 
 static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
-                         void* pooled_out, void* workspace, hipStream_t stream);
+                         void* pooled_out, void* workspace, hipStream_t stream, bool concurrent);
 
 // Folded LayerNorm (modeling_vit.py:274,281 feeding :216-218 / :250): LN(x) W^T + b is computed as
 // rstd * (x Wg^T) - (mean * rstd) * c + d inside the GEMM's epilogue, so the normalised activations are never
@@ -470,7 +470,7 @@ extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype
     hipStream_t stream = (hipStream_t)stream_;
     VIT_TRY(refresh_folds(ctx, stream));
     const int k = num_chunks(ctx, batch);
-    if (k == 1) return forward_range(ctx, pixels_dev, pixel_dtype, batch, hidden_out, pooled_out, workspace, stream);
+    if (k == 1) return forward_range(ctx, pixels_dev, pixel_dtype, batch, hidden_out, pooled_out, workspace, stream, false);
 
     // chunks on separate streams: fork after whatever the caller queued, join before returning control.
     // One chunk's kernels fill the CUs that another chunk's last round of tiles leaves idle.
@@ -495,7 +495,7 @@ extern "C" int vit_forward(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype
             rc = forward_range(ctx, (const char*)pixels_dev + (size_t)b0 * img * pes, pixel_dtype, nb,
                                (char*)hidden_out + (size_t)b0 * ctx->N * c.hidden_size * es,
                                pooled_out ? (char*)pooled_out + (size_t)b0 * c.hidden_size * es : nullptr,
-                               (char*)workspace + ws_off, st);
+                               (char*)workspace + ws_off, st, true);
         ws_off += plan_workspace(ctx, nb).total;
         if (forked) {
             hipError_t e = hipEventRecord(ctx->ev_join[i - 1], st);
@@ -526,7 +526,7 @@ extern "C" int vit_forward_static(vit_ctx* ctx, const void* pixels_dev, int pixe
 
 // the whole forward of `batch` images on one stream
 static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int batch, void* hidden_out,
-                         void* pooled_out, void* workspace, hipStream_t stream) {
+                         void* pooled_out, void* workspace, hipStream_t stream, bool concurrent) {
     const Workspace w = plan_workspace(ctx, batch);
     const vit_config& c = ctx->cfg;
     const int T = c.dtype, D = c.hidden_size, F = c.intermediate_size, N = ctx->N, H = c.num_attention_heads;
@@ -571,6 +571,7 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
         // x + Attn(LN1(x))   (modeling_vit.py:273-277)
         if (fuse) {
             GemmExt e{};
+            e.concurrent = concurrent;
             e.ln_stats = stats; e.ln_colsum = ctx->folds[l].cqkv;
             VIT_TRY(launch_ln_stats(x, stats, M, D, D, c.layer_norm_eps, T, stream));
             VIT_TRY(launch_gemm(x, ctx->folds[l].wqkv, ctx->folds[l].dqkv, nullptr, qkv, M, 3 * D, D, VIT_EPI_BIAS, T, nullptr,
@@ -580,10 +581,14 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
             VIT_TRY(launch_gemm(ln, lw.wqkv, lw.bqkv, nullptr, qkv, M, 3 * D, D, VIT_EPI_BIAS, T, nullptr, nullptr, stream));
         }
         VIT_TRY(launch_attention(qkv, cx, batch, N, H, ctx->dh, T, stream));
-        VIT_TRY(launch_gemm(cx, lw.wo, lw.bo, x, x, M, D, D, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream));
+        GemmExt er{};  // o_proj / fc2 + residual: only the chunk hint
+        er.split_k = 1;
+        er.concurrent = concurrent;
+        VIT_TRY(launch_gemm(cx, lw.wo, lw.bo, x, x, M, D, D, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream, &er));
         // x + MLP(LN2(x))    (modeling_vit.py:280-284)
         if (fuse) {
             GemmExt e{};
+            e.concurrent = concurrent;
             e.ln_stats = stats; e.ln_colsum = ctx->folds[l].c1;
             VIT_TRY(launch_ln_stats(x, stats, M, D, D, c.layer_norm_eps, T, stream));
             VIT_TRY(launch_gemm(x, ctx->folds[l].w1, ctx->folds[l].d1, nullptr, h, M, F, D, act_epi, T, nullptr, nullptr, stream, &e));
@@ -593,7 +598,7 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
         }
         // CLIP returns the un-normed stream: let the last fc2 write it straight to hidden_out
         void* dst = (clip && last) ? hidden_out : x;
-        VIT_TRY(launch_gemm(h, lw.w2, lw.b2, x, dst, M, D, F, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream));
+        VIT_TRY(launch_gemm(h, lw.w2, lw.b2, x, dst, M, D, F, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream, &er));
     }
     if (!clip) {
         // final LayerNorm over all tokens; pooled = its CLS row (modeling_vit.py:385-388, no pooler)

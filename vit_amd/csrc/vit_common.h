@@ -210,6 +210,9 @@ struct GemmExt {
     // with ln_stats[row] = (mean * rstd, rstd) and c = ln_colsum (see ln_fold_kernel, layernorm.hip)
     const float* ln_stats;   // [M][2]
     const float* ln_colsum;  // [N]
+    // the caller runs another chunk of the same forward on a second stream at the same time: keep 256-row tiles
+    // (gemm_bf16_8p.hip, few-tile planner)
+    int concurrent;
 };
 
 // C = epi(A W^T + bias (+res)); `patch` non-null => A is the pixel tensor, rows are patches,
