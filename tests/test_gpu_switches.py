@@ -4,6 +4,7 @@ small script in a child process (the child is started BEFORE it touches the GPU;
 * VIT_AMD_GEMM_GC: the column-grouped tile order of the persistent GEMM only changes WHICH workgroup computes a tile
   and when -- the output must be bit-identical to the plain mt-major order, for every epilogue that kernel has.
 * VIT_AMD_GEMM_MI: tile height of the persistent GEMM (few-tile planner of gemm_bf16_8p.hip): same bits at every height.
+* VIT_AMD_ATTN_BWD_FUSED: the one-pass attention backward against the three-launch form it replaces.
 * VIT_AMD_ATTN_RING: head_dim-80 attention on the LDS-DMA ring kernel against the staged kernel it replaces (both
   fp32 online softmax over 32-key tiles; checked to bf16 tolerance, and both against the oracle in test_gpu_kernels).
 * VIT_AMD_SPLIT_PCT / VIT_AMD_STREAMS: where vit_forward cuts the batch for its two streams changes which launch a row
@@ -82,6 +83,24 @@ for (m, n, k) in [(9232, 1024, 1024), (9232, 3072, 1024), (6304, 768, 2048), (46
 print(json.dumps(out))
 """
 
+ATTN_BWD_SCRIPT = r"""
+import json, sys, torch
+from vit_amd import ops, synth
+dev = "cuda:0"
+outs = {}
+# 197 tokens x head_dim 64: the one-pass backward kernel (more items than CUs: 24 * 12 = 288 > 256), and 224 / 128 tokens
+# (its largest / smallest sequence)
+for (b, n, h) in [(24, 197, 12), (3, 224, 2), (2, 128, 3)]:
+    qkv = synth.normal((b, n, 3 * h * 64), 13, "qkv").to(dev, torch.bfloat16)
+    do = synth.normal((b, n, h * 64), 13, "do").to(dev, torch.bfloat16)
+    out, lse = ops.attention_train(qkv, h)
+    g = ops.attention_backward(qkv, out, do, lse, h)
+    assert torch.equal(g, ops.attention_backward(qkv, out, do, lse, h))  # reproducible
+    outs[f"{b}x{n}x{h}"] = g.cpu()
+torch.save(outs, sys.argv[1])
+print(json.dumps({"ok": all(bool(torch.isfinite(o.float()).all()) for o in outs.values())}))
+"""
+
 SPLIT_SCRIPT = r"""
 import hashlib, json, torch
 from vit_amd import synth
@@ -142,6 +161,26 @@ def test_ring_attention_matches_staged_kernel(tmp_path):
         r, s = ring[key].float(), staged[key].float()
         scale = s.abs().max().item()
         assert (r - s).abs().max().item() <= scale / 128, key  # 2 bf16 ulps of the output scale
+
+
+def test_one_pass_attention_backward_matches_three_launch_form(tmp_path):
+    """VIT_AMD_ATTN_BWD_FUSED=0 keeps the delta + dQ + dK/dV launches for the shapes the one-pass kernel takes (head_dim 64,
+    97..224 tokens). Same products in the same order; delta is summed in another order (from the query's own O row in
+    registers instead of the delta kernel's butterfly), so the gradients agree to bf16 rounding, not bit for bit."""
+    import torch
+    a, b = str(tmp_path / "fused.pt"), str(tmp_path / "three.pt")
+    assert run_child(ATTN_BWD_SCRIPT, {}, a)["ok"]
+    assert run_child(ATTN_BWD_SCRIPT, {"VIT_AMD_ATTN_BWD_FUSED": "0"}, b)["ok"]
+    fused, three = torch.load(a, weights_only=True), torch.load(b, weights_only=True)
+    assert fused.keys() == three.keys() and len(fused) == 3
+    for key in fused:
+        f, t = fused[key].float(), three[key].float()
+        d = t.shape[-1] // 3
+        for j in range(3):  # dq, dk, dv have different scales
+            fj, tj = f[..., j * d:(j + 1) * d], t[..., j * d:(j + 1) * d]
+            assert (fj - tj).abs().max().item() <= tj.abs().max().item() / 64, (key, j)
+            # both are 0.24 % rms from the fp64 gradient (tools/cmp_attn_bwd.py: bf16 P / dS operands and outputs)
+            assert ((fj - tj).double().norm() / tj.double().norm()).item() <= 5e-3, (key, j)
 
 
 def test_stream_split_point_does_not_change_the_bits():

@@ -85,7 +85,10 @@ def test_layernorm_backward(rows, d, with_res):
     assert rel_err(db, br.grad) <= 5e-3
 
 
-@pytest.mark.parametrize("b,n,h,dh", [(2, 17, 4, 16), (2, 197, 3, 64), (1, 577, 2, 64), (1, 300, 2, 80), (2, 100, 2, 128)])
+@pytest.mark.parametrize("b,n,h,dh", [(2, 17, 4, 16), (2, 197, 3, 64), (1, 577, 2, 64), (1, 300, 2, 80), (2, 100, 2, 128),
+                                      # one-pass kernel (head_dim 64, 97..224 tokens): smallest, largest, exact tile multiple,
+                                      # the first length past it, and more (batch, head) items than CUs
+                                      (2, 97, 2, 64), (1, 224, 2, 64), (2, 192, 1, 64), (1, 225, 2, 64), (23, 197, 12, 64)])
 def test_attention_backward(b, n, h, dh):
     d = h * dh
     qkv = rnd((b, n, 3 * d), "qkv", 1.0)

@@ -25,6 +25,7 @@
 // order per item: bit-identical results.
 #include "vit_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -234,11 +235,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((MODE == MO
         }
         if (nitem < nitems) prefetch(nitem, nchunk);
 
-#ifdef ATTNB_LAB_SKIP  // lab only: timing without the products (results garbage)
-        const int ntiles = (nin >> 5) * (lane == 999);
-#else
         const int ntiles = nin >> 5;
-#endif
         for (int t = 0; t < ntiles; ++t) {
             // ---- S tile and dP tile: rows = 32 inner rows (registers), col = outer row (lane)
             f32x16 s, dp;
@@ -348,6 +345,284 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((MODE == MO
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// One-pass form for sequences whose operands fit the LDS whole (head_dim 64, 97..224 tokens: ViT-B/16's 197): one
+// persistent workgroup per CU takes a (batch, head) and runs BOTH halves on it back to back --
+//   phase A (= MODE_DQ):  K, V staged, each wave's 32 queries outer:  dQ
+//   phase B (= MODE_DKV): Q, dO staged, each wave's 32 keys outer:    dK, dV
+// so Q, K, V, dO come from HBM once (phase B's staging hits the L2 that phase A just filled; its outer K / V fragments
+// are read from phase A's LDS images before they are overwritten), delta = rowsum(dO * O) is computed by the waves of
+// phase A from the O rows of their own queries (no delta launch, no delta round trip), and the three launches become
+// one: 620 MB instead of 1.0 GB per call at ViT-B/16 batch 256. Same products in the same order as the two-launch
+// form; the staging of the NEXT phase is in flight in registers during the current phase's products (as PF above).
+template <int DH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_fused_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, const float* __restrict__ lse,
+    bf16_t* __restrict__ dqkv, int N, int H, int NP, int nitems, float scale_log2e, float scale) {
+    using G = BGeo<DH>;
+    constexpr int PIT = DH / 16;  // NP * CHUNKS 16-byte pieces per operand over 2 NP threads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // phase A images: K rows, V rows, K transposed-read image; phase B: Q rows, dO rows, Q and dO transposed-read images,
+    // then the lse / delta of every query. The two sets overlap (rowL / rowD lie beyond both).
+    unsigned char* const RA1 = smem;
+    unsigned char* const RA2 = RA1 + (size_t)NP * G::RS;
+    unsigned char* const TA1 = RA2 + (size_t)NP * G::RS;
+    unsigned char* const RB1 = smem;
+    unsigned char* const RB2 = RB1 + (size_t)NP * G::RS;
+    unsigned char* const TB1 = RB2 + (size_t)NP * G::RS;
+    unsigned char* const TB2 = TB1 + (size_t)NP * G::TS;
+    float* const rowL = (float*)(TB2 + (size_t)NP * G::TS);
+    float* const rowD = rowL + NP;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = blockDim.x;  // = 2 NP: every wave has 32 outer rows
+    const int r = lane & 31, hi = lane >> 5;
+    const int D = H * DH;
+    const size_t rs = (size_t)3 * D;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int tr_key = 4 * (g >> 1) + (i16 >> 2);
+    const int tr_col = ((g & 1) * 16 + 4 * (i16 & 3)) * 2;
+    const int o0 = wave * 32;
+    const int ntiles = NP >> 5;
+
+    bf16x8 pv1[PIT], pv2[PIT];
+    float pL = 0.f;
+    // staging loads of a phase: A = (K, V), B = (Q, dO) + the queries' lse
+    auto prefetch = [&](int item, bool phaseB) {
+        const int b = item / H, h = item - b * H;
+        const bf16_t* qbase = qkv + (size_t)b * N * rs + (size_t)h * DH;
+        const bf16_t* dobase = dO + (size_t)b * N * D + (size_t)h * DH;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int idx = tid + it * nthreads;
+            const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+            const int gr = row < N ? row : N - 1;  // pad rows re-read the last row; they are masked below
+            if (!phaseB) {
+                const bf16_t* p = qbase + (size_t)gr * rs + c * 8;
+                pv1[it] = *(const bf16x8*)(p + D);       // K
+                pv2[it] = *(const bf16x8*)(p + 2 * D);   // V
+            } else {
+                pv1[it] = *(const bf16x8*)(qbase + (size_t)gr * rs + c * 8);   // Q
+                pv2[it] = *(const bf16x8*)(dobase + (size_t)gr * D + c * 8);   // dO
+            }
+        }
+        if (phaseB && tid < NP) pL = tid < N ? lse[(size_t)item * N + tid] : INFINITY;  // P = exp2(.. - inf) = 0 for pad queries
+    };
+    auto commit = [&](bool phaseB) {
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int idx = tid + it * nthreads;
+            const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+            *(bf16x8*)(RA1 + (size_t)row * G::RS + c * 16) = pv1[it];
+            *(bf16x8*)(RA2 + (size_t)row * G::RS + c * 16) = pv2[it];
+            *(bf16x8*)(TA1 + (size_t)row * G::TS + c * 16) = pv1[it];
+            if (phaseB) *(bf16x8*)(TB2 + (size_t)row * G::TS + c * 16) = pv2[it];
+        }
+        if (phaseB && tid < NP) rowL[tid] = pL;
+    };
+
+    bf16x8 f1[G::KSTEPS], f2[G::KSTEPS];
+    float oL = 0.f, oD = 0.f;
+    // phase A's outer fragments: the wave's 32 queries (Q, dO), their lse, and delta from their O rows
+    auto load_outer_a = [&](int item) {
+        const int b = item / H, h = item - b * H;
+        const int orow = (o0 + r < N) ? o0 + r : N - 1;
+        const bf16_t* qp = qkv + (size_t)b * N * rs + (size_t)h * DH + (size_t)orow * rs + hi * 8;
+        const bf16_t* dp = dO + (size_t)b * N * D + (size_t)h * DH + (size_t)orow * D + hi * 8;
+        const bf16_t* op = O + (size_t)b * N * D + (size_t)h * DH + (size_t)orow * D + hi * 8;
+        bf16x8 fo[G::KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            f1[ks] = *(const bf16x8*)(qp + ks * 16);
+            f2[ks] = *(const bf16x8*)(dp + ks * 16);
+            fo[ks] = *(const bf16x8*)(op + ks * 16);
+        }
+        oL = lse[(size_t)item * N + orow];
+        float d = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d = fmaf((float)f2[ks][e], (float)fo[ks][e], d);
+        oD = d + __shfl_xor(d, 32, 64);  // the other half of the row's head dims
+    };
+    f32x16 acc1[G::DB], acc2[G::DB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc1[d][e] = 0.f; acc2[d][e] = 0.f; }
+    };
+    // one accumulator set -> bf16 rows of dqkv at column offset `col` (through the wave's LDS block: 16-byte stores)
+    auto store_acc = [&](const f32x16 (&acc)[G::DB], float mul, int item, int col) {
+        const int b = item / H, h = item - b * H;
+        unsigned char* ob = smem + (size_t)wave * 32 * G::RS;
+#pragma unroll
+        for (int d = 0; d < G::DB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = d * 32 + 8 * g4 + 4 * hi;
+                if (d0 < DH) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(acc[d][g4 * 4 + e] * mul);
+                    *(bf16x4*)(ob + (size_t)r * G::RS + d0 * 2) = v;
+                }
+            }
+        __syncthreads();  // (the block is wave-private; the barrier only pins the order of its writes and reads)
+        bf16_t* obase = dqkv + (size_t)b * N * rs + (size_t)h * DH + col;
+        for (int idx = lane; idx < 32 * G::CHUNKS; idx += 64) {
+            const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
+            const bf16x8 v = *(const bf16x8*)(ob + (size_t)row * G::RS + c * 16);
+            if (o0 + row < N) *(bf16x8*)(obase + (size_t)(o0 + row) * rs + c * 8) = v;
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item < nitems) {
+        prefetch(item, false);
+        load_outer_a(item);
+    }
+    while (item < nitems) {
+        const int nitem = item + gridDim.x;
+        // ================= phase A: dQ
+        __syncthreads();  // the previous item's last LDS reads are done
+        commit(false);
+        zero_acc();
+        if (hi == 0) rowD[o0 + r] = (o0 + r < N) ? oD : 0.f;  // for phase B (outside both image sets)
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) asm volatile("" : "+v"(f1[ks]), "+v"(f2[ks]));  // outer loads complete before the prefetch goes out
+        prefetch(item, true);
+        for (int t = 0; t < ntiles; ++t) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+            const unsigned char* p1 = RA1 + (size_t)(t * 32 + r) * G::RS + hi * 16;
+            const unsigned char* p2 = RA2 + (size_t)(t * 32 + r) * G::RS + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < G::KSTEPS; ++ks) {
+                const bf16x8 a1 = *(const bf16x8*)(p1 + ks * 32);
+                const bf16x8 a2 = *(const bf16x8*)(p2 + ks * 32);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, f1[ks], s, 0, 0, 0);    // S^T = K Q^T
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, f2[ks], dp, 0, 0, 0);  // dP^T = V dO^T
+            }
+            const int key0 = t * 32;
+            if (key0 + 32 > N) {  // wave-uniform: only the sequence's last tile has keys to mask
+                int lim = N - key0 - 4 * hi;
+                asm volatile("" : "+v"(lim));
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((e & 3) + 8 * (e >> 2) >= lim) s[e] = -INFINITY;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f(s[e] * scale_log2e - oL);
+                s[e] = p * (dp[e] - oD);  // dS^T
+            }
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                const bf16x8 dsb = pack8b(s, sk);
+#pragma unroll
+                for (int d = 0; d < G::DB; ++d)
+                    acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<G::TS>(TA1, t * 32, sk, d, tr_key, tr_col), dsb, acc1[d], 0, 0, 0);  // dQ^T += K^T dS^T
+            }
+        }
+        // phase B's outer fragments (the wave's 32 keys: K, V rows) from phase A's images, before they are overwritten
+        {
+            const unsigned char* p1 = RA1 + (size_t)(o0 + r) * G::RS + hi * 16;
+            const unsigned char* p2 = RA2 + (size_t)(o0 + r) * G::RS + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < G::KSTEPS; ++ks) {
+                f1[ks] = *(const bf16x8*)(p1 + ks * 32);
+                f2[ks] = *(const bf16x8*)(p2 + ks * 32);
+            }
+        }
+        __syncthreads();  // every wave is done with the phase A images
+        store_acc(acc1, scale, item, 0);  // dQ
+        // ================= phase B: dK, dV
+        __syncthreads();
+        commit(true);
+        zero_acc();
+        __syncthreads();
+        if (nitem < nitems) prefetch(nitem, false);
+        for (int t = 0; t < ntiles; ++t) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+            const unsigned char* p1 = RB1 + (size_t)(t * 32 + r) * G::RS + hi * 16;
+            const unsigned char* p2 = RB2 + (size_t)(t * 32 + r) * G::RS + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < G::KSTEPS; ++ks) {
+                const bf16x8 a1 = *(const bf16x8*)(p1 + ks * 32);
+                const bf16x8 a2 = *(const bf16x8*)(p2 + ks * 32);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, f1[ks], s, 0, 0, 0);    // S = Q K^T
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, f2[ks], dp, 0, 0, 0);  // dP = dO V^T
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 L = *(const f32x4*)(rowL + t * 32 + 8 * g4 + 4 * hi);
+                const f32x4 Dl = *(const f32x4*)(rowD + t * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = g4 * 4 + j;
+                    const float p = __builtin_amdgcn_exp2f(s[e] * scale_log2e - L[j]);
+                    dp[e] = p * (dp[e] - Dl[j]);  // dS
+                    s[e] = p;                     // P
+                }
+            }
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                const bf16x8 pb = pack8b(s, sk), dsb = pack8b(dp, sk);
+#pragma unroll
+                for (int d = 0; d < G::DB; ++d) {
+                    acc2[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<G::TS>(TB2, t * 32, sk, d, tr_key, tr_col), pb, acc2[d], 0, 0, 0);   // dV^T += dO^T P
+                    acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<G::TS>(TB1, t * 32, sk, d, tr_key, tr_col), dsb, acc1[d], 0, 0, 0);  // dK^T += Q^T dS
+                }
+            }
+        }
+        if (nitem < nitems) load_outer_a(nitem);
+        __syncthreads();
+        store_acc(acc1, scale, item, D);      // dK
+        __syncthreads();
+        store_acc(acc2, 1.0f, item, 2 * D);   // dV
+        item = nitem;
+    }
+}
+
+// the one-pass kernel takes this problem: head_dim 64, every wave of 4..7 has 32 outer rows, everything fits the LDS
+template <int DH>
+constexpr int fused_row_bytes() { return 2 * BGeo<DH>::RS + 2 * BGeo<DH>::TS + 8; }
+inline bool bwd_fused_eligible(int N, int head_dim) {
+    const int np = (N + 31) / 32 * 32;
+    return head_dim == 64 && np >= 128 && np <= 256 && (size_t)np * fused_row_bytes<64>() <= 156 * 1024;
+}
+
+int launch_bwd_fused64(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int batch, int N, int H,
+                       hipStream_t stream) {
+    constexpr int DH = 64;
+    const int NP = (N + 31) / 32 * 32;
+    const size_t lds = (size_t)NP * fused_row_bytes<DH>();
+    auto kern = attn_bwd_fused_kernel<DH>;
+    static PerDeviceInt attr_set;
+    std::atomic<int>* as = attr_set.slot();
+    if (!as || !as->load(std::memory_order_relaxed)) {
+        VIT_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        if (as) as->store(1, std::memory_order_relaxed);
+    }
+    int ncu = 0;
+    VIT_TRY_RC(vit_cu_count(&ncu));
+    const long nitems = (long)batch * H;
+    VIT_REQUIRE(nitems < (1L << 31), "attention_bwd: too many (batch, head) items");
+    const int grid = nitems < ncu ? (int)nitems : ncu;
+    const float scale = 1.0f / sqrtf((float)DH);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NP * 2), lds, stream, (const bf16_t*)qkv, (const bf16_t*)O, (const bf16_t*)dO, lse,
+                       (bf16_t*)dqkv, N, H, NP, (int)nitems, scale * LOG2E, scale);
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
 // delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]
 template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
@@ -451,6 +726,9 @@ int launch_bwd_part(const void* qkv, const void* dO, const float* lse, const flo
 template <int DH>
 int launch_bwd(const void* qkv, const void* O, const void* dO, const float* lse, float* delta, void* dqkv, int batch,
                int N, int H, hipStream_t stream) {
+    // VIT_AMD_ATTN_BWD_FUSED=0: the three-launch form everywhere (A/B switch; tests/test_gpu_switches.py)
+    static const bool fused_on = !(getenv("VIT_AMD_ATTN_BWD_FUSED") && atoi(getenv("VIT_AMD_ATTN_BWD_FUSED")) == 0);
+    if (fused_on && bwd_fused_eligible(N, DH)) return launch_bwd_fused64(qkv, O, dO, lse, dqkv, batch, N, H, stream);
     constexpr int CPH = DH / 8;
     const long total = (long)batch * N * H * (((CPH & (CPH - 1)) == 0 && CPH <= 16) ? CPH : 1);
     hipLaunchKernelGGL(attn_delta_kernel<DH>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)O,
