@@ -470,13 +470,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void a
                     *(bf16x4*)(ob + (size_t)r * G::RS + d0 * 2) = v;
                 }
             }
-        __syncthreads();  // (the block is wave-private; the barrier only pins the order of its writes and reads)
+        // the block is wave-private and a wave's LDS operations execute in order: no barrier, only the compiler is held
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bf16_t* obase = dqkv + (size_t)b * N * rs + (size_t)h * DH + col;
         for (int idx = lane; idx < 32 * G::CHUNKS; idx += 64) {
             const int row = idx / G::CHUNKS, c = idx - row * G::CHUNKS;
             const bf16x8 v = *(const bf16x8*)(ob + (size_t)row * G::RS + c * 16);
             if (o0 + row < N) *(bf16x8*)(obase + (size_t)(o0 + row) * rs + c * 8) = v;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are in before the wave writes its block again
     };
 
     int item = blockIdx.x;
@@ -585,7 +587,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void a
         if (nitem < nitems) load_outer_a(nitem);
         __syncthreads();
         store_acc(acc1, scale, item, D);      // dK
-        __syncthreads();
         store_acc(acc2, 1.0f, item, 2 * D);   // dV
         item = nitem;
     }
