@@ -119,12 +119,14 @@ def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
 
 def pmc_traffic_bytes(kernel_key: str):
     """Bytes beyond L2 per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r02d_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same script, with
+    (the newest profiles/r*_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same script, with
     the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced
     read). Counters cannot be read from inside the process, so this is the recorded figure for
     the same workload, or None when the file or the kernel is missing."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02d_traffic.json")) as f:
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]  # named per round: r03a > r02d
+        with open(newest) as f:
             rec = json.load(f)["per_launch_kb"].get(kernel_key)
         return None if rec is None else (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
     except (OSError, KeyError, ValueError):

@@ -10,10 +10,10 @@ Only library kernels are kept, grouped by the bench's kernel names; launches of 
 import csv, glob, json, os, sys
 
 GROUPS = [  # bench name, substring of the kernel name
-    ("gemm_fc1_gelu", "gemm8p_persist_kernel<1, 0, true>"),
-    ("gemm_qkv", "gemm8p_persist_kernel<0, 0, true>"),
-    ("gemm_o_proj_res+gemm_fc2_res", "gemm8p_persist_kernel<3, 0, false>"),
-    ("patch_embed", "gemm8p_persist_kernel<100, 0, false>"),
+    ("gemm_fc1_gelu", "gemm8p_persist_kernel<1, 0, true"),
+    ("gemm_qkv", "gemm8p_persist_kernel<0, 0, true"),
+    ("gemm_o_proj_res+gemm_fc2_res", "gemm8p_persist_kernel<3, 0, false"),
+    ("patch_embed", "gemm8p_persist_kernel<100, 0, false"),
     ("attention", "attention_dh64_kernel"),
     ("layernorm_stats", "ln_stats_kernel"),
     ("layernorm", "layernorm_kernel"),
