@@ -2,6 +2,7 @@
 // timing-only variants (ATTN_VAR, see attention_dh64.hip) on packed random QKV.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DATTN_VAR=n] tools/attn_lab.hip -o tools/attn_lab
 //   ./tools/attn_lab <batch> <tokens> <heads> [reps]
+#define ATTN_VAR 0  // the timing-only variants (softmax / products / waits removed) lived in attention_dh64.hip until round 3 (history: f9e38f8)
 #include "../vit_amd/csrc/attention_dh64.hip"
 #include <stdarg.h>
 #include <string.h>

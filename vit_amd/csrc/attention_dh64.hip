@@ -24,10 +24,7 @@
 //  * one raw s_barrier per tile; waves without queries (N = 197: the 8th) only load.
 #include "vit_common.h"
 #include <math.h>
-
-#ifndef ATTN_VAR
-#define ATTN_VAR 0  // lab only (tools/attn_lab.hip): timing-only variants, results garbage
-#endif
+#include <type_traits>
 
 namespace {
 
@@ -38,6 +35,7 @@ constexpr int SLOT = 8192;     // one tile: K 32 x 128 B, then V 32 x 128 B
 constexpr int NW = 8;          // waves per workgroup
 constexpr int NQ = 4;          // Q DMA pieces per wave and item
 constexpr int QSLOT = 4096;    // one wave's 32 query rows x 128 B
+constexpr float kDeferLog2 = 6.0f;  // the running max is left alone until a score outgrows it by more than this (base 2)
 
 // Where Q, K, V live: operand bases and byte strides (batch, head, token). The packed QKV GEMM
 // output [B*N, 3*H*64] is what the library uses; a head-major [3][B][H][N][64] source was timed with
@@ -166,104 +164,97 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
     for (int s = 0; s < R - 1; ++s) dma_next(s);
 
-    f32x16 o[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[2];                      // written by the first tile of every item
+    float m_run = 0.f, l_run = 0.f;
 
     int slot = 0;          // ring slot of the current tile
     int pslot = R - 1;     // ring slot the next DMA goes to
     bool prev_active = false;  // did this wave store outputs for the previous item
-    for (int j = 0; j < nmy; ++j) {
-        const bool active = q0 < N;  // wave-uniform
-        for (int p = 0; p < nt; ++p) {
-            // ---- counted wait: everything up to this wave's piece of the current tile has landed.
-            // Younger operations that may stay in flight: R-2 DMAs; while p <= R-2 also the previous
-            // item's ST stores (if this wave had queries in it) and, from p = 1, the NQ loads of the Q prefetch.
-#if ATTN_VAR != 4 && ATTN_VAR != 5
-            {
-                const bool inwin = p <= R - 2;
-                const bool stin = inwin && prev_active;
-                const bool qin = inwin && p >= 1;
-                if (stin) {
-                    if (qin) wait_vm<R - 2 + NQ + ST>(); else wait_vm<R - 2 + ST>();
-                } else {
-                    if (qin) wait_vm<R - 2 + NQ>(); else wait_vm<R - 2>();
-                }
+    // One tile step. FIRST (p = 0 of an item): the running max is the tile's own, O and l start from this tile (the PV
+    // products take a zero accumulator, nothing is zeroed or rescaled).
+    auto tile_step = [&](auto FIRSTC, int j, int p, bool active) {
+        constexpr bool FIRST = decltype(FIRSTC)::value;
+        // ---- counted wait: everything up to this wave's piece of the current tile has landed.
+        // Younger operations that may stay in flight: R-2 DMAs; while p <= R-2 also the previous
+        // item's ST stores (if this wave had queries in it) and, from p = 1, the NQ loads of the Q prefetch.
+        {
+            const bool inwin = p <= R - 2;
+            const bool stin = inwin && prev_active;
+            const bool qin = inwin && p >= 1;
+            if (stin) {
+                if (qin) wait_vm<R - 2 + NQ + ST>(); else wait_vm<R - 2 + ST>();
+            } else {
+                if (qin) wait_vm<R - 2 + NQ>(); else wait_vm<R - 2>();
             }
-            asm volatile("s_barrier" ::: "memory");  // every wave's piece landed; the previous tile's slot is free
-#endif
-            if (p == 0) {
-                // this item's Q fragments (DMA issued one item ago, older than the tile just waited
-                // for) -> registers; then the slot is free for the next item's Q (clamped to the last
-                // item so every item issues the same number of DMAs)
+        }
+        asm volatile("s_barrier" ::: "memory");  // every wave's piece landed; the previous tile's slot is free
+        if constexpr (FIRST) {
+            // this item's Q fragments (DMA issued one item ago, older than the tile just waited
+            // for) -> registers; then the slot is free for the next item's Q (clamped to the last
+            // item so every item issues the same number of DMAs)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qslot + kro[ks]);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
-                const int jn = j + 1 < nmy ? j + 1 : j;
-                int nqb;
-                const int nbh = item_bh(jn, &nqb);
-                dma_q(item_rsrc(src.q, nbh), (nqb * NW + wave) * 32);
-            }
-#if ATTN_VAR != 5
-            dma_next(pslot);
-#endif
-            pslot = pslot + 1 == R ? 0 : pslot + 1;
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qslot + kro[ks]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
+            const int jn = j + 1 < nmy ? j + 1 : j;
+            int nqb;
+            const int nbh = item_bh(jn, &nqb);
+            dma_q(item_rsrc(src.q, nbh), (nqb * NW + wave) * 32);
+        }
+        dma_next(pslot);
+        pslot = pslot + 1 == R ? 0 : pslot + 1;
 
-            if (active) {
-                const unsigned char* Kb = smem + slot * SLOT;
-                const unsigned kb_lds = smem_lds + (unsigned)(slot * SLOT);
-                // ---- S^T tile: 32 keys x 32 queries ----
-                f32x16 s;
+        if (active) {
+            const unsigned char* Kb = smem + slot * SLOT;
+            const unsigned kb_lds = smem_lds + (unsigned)(slot * SLOT);
+            // ---- S^T tile: 32 keys x 32 queries ----
+            f32x16 s;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#if ATTN_VAR == 3
-                for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(s[e]));
-#else
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(Kb + kro[ks]);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-                }
-#endif
-#if ATTN_VAR != 2
-                // V^T fragments of both key halves by ds_read_b64_tr_b16, issued now (the tile landed before
-                // the barrier) and waited for just before the PV products, so their latency hides behind
-                // the softmax. Inline asm: through the builtin the compiler orders every such read behind
-                // vmcnt(0) (it may alias a DMA target), which would drain the ring it reads from.
-                short4v vl[8];
-                {
-                    const unsigned va0 = kb_lds + vro[0], va1 = kb_lds + vro[1];
-                    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
-                                 "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
-                                 "ds_read_b64_tr_b16 %4, %8 offset:2048\n\tds_read_b64_tr_b16 %5, %8 offset:3072\n\t"
-                                 "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072"
-                                 : "=&v"(vl[0]), "=&v"(vl[1]), "=&v"(vl[2]), "=&v"(vl[3]), "=&v"(vl[4]), "=&v"(vl[5]),
-                                   "=&v"(vl[6]), "=&v"(vl[7])
-                                 : "v"(va0), "v"(va1)
-                                 : "memory");
-                }
-#endif
-                const int key0 = p * 32;
-                if (key0 + 32 > N) {  // wave-uniform: only the last tile of the sequence
-                    // (the limit is made opaque here: hoisted out of the loops, the 16 lane masks live in 32 SGPRs and
-                    // push the loop's own scalars into spill lanes)
-                    int lim = N - key0 - 4 * hi;
-                    asm volatile("" : "+v"(lim));
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(Kb + kro[ks]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            // V^T fragments of both key halves by ds_read_b64_tr_b16, issued now (the tile landed before
+            // the barrier) and waited for just before the PV products, so their latency hides behind
+            // the softmax. Inline asm: through the builtin the compiler orders every such read behind
+            // vmcnt(0) (it may alias a DMA target), which would drain the ring it reads from.
+            short4v vl[8];
+            {
+                const unsigned va0 = kb_lds + vro[0], va1 = kb_lds + vro[1];
+                asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+                             "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+                             "ds_read_b64_tr_b16 %4, %8 offset:2048\n\tds_read_b64_tr_b16 %5, %8 offset:3072\n\t"
+                             "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072"
+                             : "=&v"(vl[0]), "=&v"(vl[1]), "=&v"(vl[2]), "=&v"(vl[3]), "=&v"(vl[4]), "=&v"(vl[5]),
+                               "=&v"(vl[6]), "=&v"(vl[7])
+                             : "v"(va0), "v"(va1)
+                             : "memory");
+            }
+            const int key0 = p * 32;
+            if (key0 + 32 > N) {  // wave-uniform: only the last tile of the sequence
+                // (the limit is made opaque here: hoisted out of the loops, the 16 lane masks live in 32 SGPRs and
+                // push the loop's own scalars into spill lanes)
+                int lim = N - key0 - 4 * hi;
+                asm volatile("" : "+v"(lim));
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if ((e & 3) + 8 * (e >> 2) >= lim) s[e] = -INFINITY;
-                }
-#if ATTN_VAR != 1
-                float mx = s[0];
+                for (int e = 0; e < 16; ++e)
+                    if ((e & 3) + 8 * (e >> 2) >= lim) s[e] = -INFINITY;
+            }
+            float mx = s[0];
 #pragma unroll
-                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
-                mx = max_across_halves(mx);
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
+            mx = max_across_halves(mx);
+            if constexpr (FIRST) {
+                m_run = mx * scale_log2e;
+            } else {
+                // The running max follows a query's scores only when one of them outgrows it by more than kDeferLog2
+                // (base-2 units): until then P = exp2(S c - m_run) <= 2^kDeferLog2, which bf16 P and the fp32 sums hold
+                // just as well, and the O / l rescale -- 18 instructions that random scores trigger in nearly every
+                // tile (one of a wave's 32 queries meets a new maximum) -- runs only when it has to. Exact either way:
+                // when the branch fires everything at the old max is scaled once (cdna_hip_programming.md T13).
                 const float m_new = fmaxf(m_run, mx * scale_log2e);
-                // rescale O / l only when some query of the wave saw a larger score (exact, wave-uniform)
-                if (__any(m_new > m_run)) {
+                if (__any(m_new > m_run + kDeferLog2)) {
                     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                     m_run = m_new;
                     l_run *= alpha;
@@ -272,38 +263,44 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
                         for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
                 }
-                float psum = 0.f;
+            }
+            float psum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    s[e] = __builtin_amdgcn_exp2f(s[e] * scale_log2e - m_run);
-                    psum += s[e];
-                }
-                l_run += psum;
-#endif
-                // ---- O^T += V^T P^T ----
-#if ATTN_VAR == 2
+            for (int e = 0; e < 16; ++e) {
+                s[e] = __builtin_amdgcn_exp2f(s[e] * scale_log2e - m_run);
+                psum += s[e];
+            }
+            if constexpr (FIRST) l_run = psum; else l_run += psum;
+            // ---- O^T += V^T P^T ----
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(vl[0]), "+v"(vl[1]), "+v"(vl[2]), "+v"(vl[3]), "+v"(vl[4]), "+v"(vl[5]), "+v"(vl[6]), "+v"(vl[7])::"memory");
 #pragma unroll
-                for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(s[e]));
-#else
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(vl[0]), "+v"(vl[1]), "+v"(vl[2]), "+v"(vl[3]), "+v"(vl[4]), "+v"(vl[5]), "+v"(vl[6]), "+v"(vl[7])::"memory");
-#pragma unroll
-                for (int sk = 0; sk < 2; ++sk) {
-                    const bf16x8 pb = pack8(s, sk);
-                    const short8v b0 = __builtin_shufflevector(vl[4 * sk + 0], vl[4 * sk + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const short8v b1 = __builtin_shufflevector(vl[4 * sk + 2], vl[4 * sk + 3], 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int sk = 0; sk < 2; ++sk) {
+                const bf16x8 pb = pack8(s, sk);
+                const short8v b0 = __builtin_shufflevector(vl[4 * sk + 0], vl[4 * sk + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const short8v b1 = __builtin_shufflevector(vl[4 * sk + 2], vl[4 * sk + 3], 0, 1, 2, 3, 4, 5, 6, 7);
+                if (FIRST && sk == 0) {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), pb, z, 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), pb, z, 0, 0, 0);
+                } else {
                     o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), pb, o[0], 0, 0, 0);
                     o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), pb, o[1], 0, 0, 0);
                 }
-#endif
             }
-            slot = slot + 1 == R ? 0 : slot + 1;
         }
+        slot = slot + 1 == R ? 0 : slot + 1;
+    };
+
+    for (int j = 0; j < nmy; ++j) {
+        const bool active = q0 < N;  // wave-uniform
+        tile_step(std::true_type{}, j, 0, active);
+        for (int p = 1; p < nt; ++p) tile_step(std::false_type{}, j, p, active);
 
         // ---- item finished: ST stores per active wave, never waited for explicitly ----
         if (active) {
             const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-            const float inv = 1.0f / l_tot;
+            const float inv = __builtin_amdgcn_rcpf(l_tot);  // 1 ulp; the result is rounded to bf16
             const int b = bh / H, h = bh - b * H;
             if constexpr (LSE) {
                 if (hi == 0 && q0 + r < N) lse[(size_t)bh * N + q0 + r] = m_run + log2f(l_tot);
@@ -311,8 +308,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             {
                 // The lane halves trade 8-byte pieces (v_permlane32_swap) so that every lane holds 8 consecutive head
                 // dims: 16-byte stores, four per item instead of eight, each row's 128 bytes touched by four instructions.
-                bf16_t* op = out + ((size_t)b * N + q0 + r) * D + (size_t)h * DH + 8 * hi;
-                const bool row_ok = q0 + r < N;
+                // Through a buffer resource over the image's rows of this head: a 32-bit lane offset, rows >= N out of range.
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(out + (size_t)b * N * D + (size_t)h * DH), 0, (unsigned)(N - 1) * (unsigned)(D * 2) + (unsigned)(DH * 2), 0x00020000);
+                const unsigned ooff = (q0 + r < N) ? (unsigned)(q0 + r) * (unsigned)(D * 2) + (unsigned)(16 * hi) : 0x80000000u;
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     unsigned w[4][2];
@@ -335,16 +334,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             pk[k] = (unsigned)sw[0];
                             pk[2 + k] = (unsigned)sw[1];
                         }
-                        if (row_ok) *(u32x4*)(op + d * 32 + 16 * pr) = pk;
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, (int)(ooff + (unsigned)(d * 64 + 32 * pr)), 0, 0);
                     }
                 }
             }
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-            m_run = -INFINITY;
-            l_run = 0.f;
         }
         prev_active = active;
         if (j + 1 < nmy) {
