@@ -31,7 +31,6 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int DH = 64;
 constexpr int R = 5;           // ring depth, tiles
-constexpr int DD = R - 2;      // tiles the DMA runs ahead of the step that consumes them
 constexpr int SLOT = 8192;     // one tile: K 32 x 128 B, then V 32 x 128 B
 constexpr int NW = 8;          // waves per workgroup
 constexpr int NQ = 4;          // Q DMA pieces per wave and item
@@ -163,257 +162,187 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
     };
 #pragma unroll
-    for (int s = 0; s < DD; ++s) dma_next(s);
+    for (int s = 0; s < R - 1; ++s) dma_next(s);
 
-    f32x16 o[2];
+    f32x16 o[2];                      // written by the first tile of every item
     float m_run = 0.f, l_run = 0.f;
-    f32x16 s;              // scores of the tile in hand (group B: kept across the barrier until its second half runs)
 
     int slot = 0;          // ring slot of the current tile
-    int pslot = DD;        // ring slot the next DMA goes to
+    int pslot = R - 1;     // ring slot the next DMA goes to
     bool prev_active = false;  // did this wave store outputs for the previous item
-
-    // ---- pieces of a tile step
-    auto wait_tile = [&](bool stin, bool qin) {
-        // counted wait: everything up to this wave's piece of the current tile has landed; the DD-1 younger tile DMAs,
-        // and the previous item's ST stores / the NQ loads of the Q prefetch while those are younger, stay in flight
-        if (stin) {
-            if (qin) wait_vm<DD - 1 + NQ + ST>(); else wait_vm<DD - 1 + ST>();
-        } else {
-            if (qin) wait_vm<DD - 1 + NQ>(); else wait_vm<DD - 1>();
-        }
-        asm volatile("s_barrier" ::: "memory");  // every wave's piece landed; the slot the next DMA takes is free
-    };
-    auto load_q = [&](int j) {
-        // this item's Q fragments (DMA issued one item ago, older than the tile just waited for) -> registers; then
-        // the slot is free for the next item's Q (clamped to the last item so every item issues the same number of DMAs)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qslot + kro[ks]);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
-        const int jn = j + 1 < nmy ? j + 1 : j;
-        int nqb;
-        const int nbh = item_bh(jn, &nqb);
-        dma_q(item_rsrc(src.q, nbh), (nqb * NW + wave) * 32);
-    };
-    // S^T tile (32 keys x 32 queries) of the tile in ring slot `slt`
-    auto qk = [&](int slt) {
-        const unsigned char* Kb = smem + slt * SLOT;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(Kb + kro[ks]);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-        }
-    };
-    // V^T fragments of both key halves by ds_read_b64_tr_b16. Inline asm: through the builtin the compiler orders every
-    // such read behind vmcnt(0) (it may alias a DMA target), which would drain the ring it reads from.
-    auto v_read = [&](int slt, short4v (&vl)[8]) {
-        const unsigned kb_lds = smem_lds + (unsigned)(slt * SLOT);
-        const unsigned va0 = kb_lds + vro[0], va1 = kb_lds + vro[1];
-        asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
-                     "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
-                     "ds_read_b64_tr_b16 %4, %8 offset:2048\n\tds_read_b64_tr_b16 %5, %8 offset:3072\n\t"
-                     "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072"
-                     : "=&v"(vl[0]), "=&v"(vl[1]), "=&v"(vl[2]), "=&v"(vl[3]), "=&v"(vl[4]), "=&v"(vl[5]), "=&v"(vl[6]), "=&v"(vl[7])
-                     : "v"(va0), "v"(va1)
-                     : "memory");
-    };
-    // first half of the softmax: key mask of the sequence's last tile, the tile's row maxima, the running max.
-    // FIRST (tile 0 of an item): the running max is the tile's own; nothing to rescale.
-    auto sm_max = [&](auto FIRSTC, int p) {
+    // One tile step. FIRST (p = 0 of an item): the running max is the tile's own, O and l start from this tile (the PV
+    // products take a zero accumulator, nothing is zeroed or rescaled).
+    auto tile_step = [&](auto FIRSTC, int j, int p, bool active) {
         constexpr bool FIRST = decltype(FIRSTC)::value;
-        const int key0 = p * 32;
-        if (key0 + 32 > N) {  // wave-uniform: only the last tile of the sequence
-            // (the limit is made opaque here: hoisted out of the loops, the 16 lane masks live in 32 SGPRs and
-            // push the loop's own scalars into spill lanes)
-            int lim = N - key0 - 4 * hi;
-            asm volatile("" : "+v"(lim));
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if ((e & 3) + 8 * (e >> 2) >= lim) s[e] = -INFINITY;
-        }
-        float mx = s[0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
-        mx = max_across_halves(mx);
-        if constexpr (FIRST) {
-            m_run = mx * scale_log2e;
-        } else {
-            // The running max follows a query's scores only when one of them outgrows it by more than kDeferLog2
-            // (base-2 units): until then P = exp2(S c - m_run) <= 2^kDeferLog2, which bf16 P and the fp32 sums hold
-            // just as well, and the O / l rescale -- 18 instructions that random scores trigger in nearly every
-            // tile (one of a wave's 32 queries meets a new maximum) -- runs only when it has to. Exact either way:
-            // when the branch fires everything at the old max is scaled once (cdna_hip_programming.md T13).
-            const float m_new = fmaxf(m_run, mx * scale_log2e);
-            if (__any(m_new > m_run + kDeferLog2)) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-            }
-        }
-    };
-    // second half: P = exp2(S c - m), row sums, O^T += V^T P^T. ZERO: O and l start from this tile.
-    auto sm_exp_pv = [&](auto ZEROC, short4v (&vl)[8]) {
-        constexpr bool ZERO = decltype(ZEROC)::value;
-        float psum = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s[e] = __builtin_amdgcn_exp2f(s[e] * scale_log2e - m_run);
-            psum += s[e];
-        }
-        if constexpr (ZERO) l_run = psum; else l_run += psum;
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vl[0]), "+v"(vl[1]), "+v"(vl[2]), "+v"(vl[3]), "+v"(vl[4]), "+v"(vl[5]), "+v"(vl[6]), "+v"(vl[7])::"memory");
-#pragma unroll
-        for (int sk = 0; sk < 2; ++sk) {
-            const bf16x8 pb = pack8(s, sk);
-            const short8v b0 = __builtin_shufflevector(vl[4 * sk + 0], vl[4 * sk + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-            const short8v b1 = __builtin_shufflevector(vl[4 * sk + 2], vl[4 * sk + 3], 0, 1, 2, 3, 4, 5, 6, 7);
-            if (ZERO && sk == 0) {
-                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), pb, z, 0, 0, 0);
-                o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), pb, z, 0, 0, 0);
+        // ---- counted wait: everything up to this wave's piece of the current tile has landed.
+        // Younger operations that may stay in flight: R-2 DMAs; while p <= R-2 also the previous
+        // item's ST stores (if this wave had queries in it) and, from p = 1, the NQ loads of the Q prefetch.
+        {
+            const bool inwin = p <= R - 2;
+            const bool stin = inwin && prev_active;
+            const bool qin = inwin && p >= 1;
+            if (stin) {
+                if (qin) wait_vm<R - 2 + NQ + ST>(); else wait_vm<R - 2 + ST>();
             } else {
-                o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), pb, o[0], 0, 0, 0);
-                o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), pb, o[1], 0, 0, 0);
+                if (qin) wait_vm<R - 2 + NQ>(); else wait_vm<R - 2>();
             }
         }
-    };
-    // an item's output: ST stores per wave with queries, never waited for explicitly
-    auto store_item = [&](int ibh, int iq0) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = __builtin_amdgcn_rcpf(l_tot);  // 1 ulp; the result is rounded to bf16
-        const int b = ibh / H, h = ibh - b * H;
-        if constexpr (LSE) {
-            if (hi == 0 && iq0 + r < N) lse[(size_t)ibh * N + iq0 + r] = m_run + log2f(l_tot);
+        asm volatile("s_barrier" ::: "memory");  // every wave's piece landed; the previous tile's slot is free
+        if constexpr (FIRST) {
+            // this item's Q fragments (DMA issued one item ago, older than the tile just waited
+            // for) -> registers; then the slot is free for the next item's Q (clamped to the last
+            // item so every item issues the same number of DMAs)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qslot + kro[ks]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
+            const int jn = j + 1 < nmy ? j + 1 : j;
+            int nqb;
+            const int nbh = item_bh(jn, &nqb);
+            dma_q(item_rsrc(src.q, nbh), (nqb * NW + wave) * 32);
         }
-        // The lane halves trade 8-byte pieces (v_permlane32_swap) so that every lane holds 8 consecutive head
-        // dims: 16-byte stores, four per item instead of eight, each row's 128 bytes touched by four instructions.
-        // Through a buffer resource over the image's rows of this head: a 32-bit lane offset, rows >= N out of range.
-        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(out + (size_t)b * N * D + (size_t)h * DH), 0, (unsigned)(N - 1) * (unsigned)(D * 2) + (unsigned)(DH * 2), 0x00020000);
-        const unsigned ooff = (iq0 + r < N) ? (unsigned)(iq0 + r) * (unsigned)(D * 2) + (unsigned)(16 * hi) : 0x80000000u;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            unsigned w[4][2];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                bf16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[d][g4 * 4 + e] * inv);
-                const u32x2 u = __builtin_bit_cast(u32x2, v);
-                w[g4][0] = u[0];
-                w[g4][1] = u[1];
-            }
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                // lanes < 32 keep piece 2pr and receive their partner's; lanes >= 32 keep piece 2pr+1
-                u32x4 pk;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(w[2 * pr][k], w[2 * pr + 1][k], false, false);
-                    pk[k] = (unsigned)sw[0];
-                    pk[2 + k] = (unsigned)sw[1];
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, (int)(ooff + (unsigned)(d * 64 + 32 * pr)), 0, 0);
-            }
-        }
-    };
+        dma_next(pslot);
+        pslot = pslot + 1 == R ? 0 : pslot + 1;
 
-    if (wave < NW / 2) {
-        // ================= group A (waves 0..3): a tile is finished inside its own step:  QK, softmax, PV
-        auto step_a = [&](auto FIRSTC, int j, int p, bool active) {
-            constexpr bool FIRST = decltype(FIRSTC)::value;
-            wait_tile(p <= DD - 1 && prev_active, p >= 1 && p <= DD - 1);
-            if constexpr (FIRST) load_q(j);
-            dma_next(pslot);
-            pslot = pslot + 1 == R ? 0 : pslot + 1;
-            if (active) {
-                short4v vl[8];
-                qk(slot);
-                v_read(slot, vl);  // issued now, waited for just before the PV products: the latency hides behind the softmax
-                sm_max(FIRSTC, p);
-                sm_exp_pv(FIRSTC, vl);
+        if (active) {
+            const unsigned char* Kb = smem + slot * SLOT;
+            const unsigned kb_lds = smem_lds + (unsigned)(slot * SLOT);
+            // ---- S^T tile: 32 keys x 32 queries ----
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(Kb + kro[ks]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             }
-            slot = slot + 1 == R ? 0 : slot + 1;
-        };
-        for (int j = 0; j < nmy; ++j) {
-            const bool active = q0 < N;  // wave-uniform
-            step_a(std::true_type{}, j, 0, active);
-            for (int p = 1; p < nt; ++p) step_a(std::false_type{}, j, p, active);
-            if (active) store_item(bh, q0);
-            prev_active = active;
-            if (j + 1 < nmy) {
-                bh = item_bh(j + 1, &qb);
-                q0 = (qb * NW + wave) * 32;
+            // V^T fragments of both key halves by ds_read_b64_tr_b16, issued now (the tile landed before
+            // the barrier) and waited for just before the PV products, so their latency hides behind
+            // the softmax. Inline asm: through the builtin the compiler orders every such read behind
+            // vmcnt(0) (it may alias a DMA target), which would drain the ring it reads from.
+            short4v vl[8];
+            {
+                const unsigned va0 = kb_lds + vro[0], va1 = kb_lds + vro[1];
+                asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+                             "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+                             "ds_read_b64_tr_b16 %4, %8 offset:2048\n\tds_read_b64_tr_b16 %5, %8 offset:3072\n\t"
+                             "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %9 offset:3072"
+                             : "=&v"(vl[0]), "=&v"(vl[1]), "=&v"(vl[2]), "=&v"(vl[3]), "=&v"(vl[4]), "=&v"(vl[5]),
+                               "=&v"(vl[6]), "=&v"(vl[7])
+                             : "v"(va0), "v"(va1)
+                             : "memory");
             }
-        }
-    } else {
-        // ================= group B (waves 4..7): HALF A STEP BEHIND. A step is  [exp / sums / PV of the PREVIOUS tile]
-        // [QK and row maxima of this tile]: the two waves a SIMD holds (w and w + 4) leave every barrier in different
-        // halves of the tile, so one wave's products run under the other's exponentials instead of both waves queueing
-        // for the matrix pipe and then for the vector pipe together (MI355X_MICROARCH.md, Two waves per SIMD, item 9).
-        // The pending tile's V rows are read AFTER the barrier of the next step, which is why the DMA runs DD = R - 2
-        // tiles ahead and not R - 1: the slot a step's DMA takes was last read two steps ago by every wave.
-        int pend_slot = 0;
-        bool pend = false;            // a tile's second half is outstanding (wave-uniform)
-        int pbh = bh, pq0 = q0;       // item of the pending tile
-        auto step_b = [&](auto FIRSTC, int j, int p, bool active) {
-            constexpr bool FIRST = decltype(FIRSTC)::value;
-            // this group's stores and Q loads of an item boundary are issued in step 0 of the NEXT item, behind its tile DMA
-            wait_tile(p >= 1 && p <= DD && prev_active, p >= 1 && p <= DD);
-            dma_next(pslot);
-            pslot = pslot + 1 == R ? 0 : pslot + 1;
-            if (pend) {
-                short4v vl[8];
-                v_read(pend_slot, vl);
-                sm_exp_pv(std::false_type{}, vl);
+            const int key0 = p * 32;
+            if (key0 + 32 > N) {  // wave-uniform: only the last tile of the sequence
+                // (the limit is made opaque here: hoisted out of the loops, the 16 lane masks live in 32 SGPRs and
+                // push the loop's own scalars into spill lanes)
+                int lim = N - key0 - 4 * hi;
+                asm volatile("" : "+v"(lim));
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((e & 3) + 8 * (e >> 2) >= lim) s[e] = -INFINITY;
             }
+            float mx = s[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
+            mx = max_across_halves(mx);
             if constexpr (FIRST) {
-                if (pend) {
-                    store_item(pbh, pq0);
+                m_run = mx * scale_log2e;
+            } else {
+                // The running max follows a query's scores only when one of them outgrows it by more than kDeferLog2
+                // (base-2 units): until then P = exp2(S c - m_run) <= 2^kDeferLog2, which bf16 P and the fp32 sums hold
+                // just as well, and the O / l rescale -- 18 instructions that random scores trigger in nearly every
+                // tile (one of a wave's 32 queries meets a new maximum) -- runs only when it has to. Exact either way:
+                // when the branch fires everything at the old max is scaled once (cdna_hip_programming.md T13).
+                const float m_new = fmaxf(m_run, mx * scale_log2e);
+                if (__any(m_new > m_run + kDeferLog2)) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    l_run *= alpha;
 #pragma unroll
                     for (int d = 0; d < 2; ++d)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-                    l_run = 0.f;
+                        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
                 }
-                prev_active = pend;
-                load_q(j);
             }
-            if (active) {
-                qk(slot);
-                sm_max(FIRSTC, p);
+            float psum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[e] = __builtin_amdgcn_exp2f(s[e] * scale_log2e - m_run);
+                psum += s[e];
             }
-            pend = active;
-            pend_slot = slot;
-            slot = slot + 1 == R ? 0 : slot + 1;
-        };
+            if constexpr (FIRST) l_run = psum; else l_run += psum;
+            // ---- O^T += V^T P^T ----
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(vl[0]), "+v"(vl[1]), "+v"(vl[2]), "+v"(vl[3]), "+v"(vl[4]), "+v"(vl[5]), "+v"(vl[6]), "+v"(vl[7])::"memory");
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-        for (int j = 0; j < nmy; ++j) {
-            const bool active = q0 < N;  // wave-uniform
-            step_b(std::true_type{}, j, 0, active);
-            pbh = bh;
-            pq0 = q0;
-            for (int p = 1; p < nt; ++p) step_b(std::false_type{}, j, p, active);
-            if (j + 1 < nmy) {
-                bh = item_bh(j + 1, &qb);
-                q0 = (qb * NW + wave) * 32;
+            for (int sk = 0; sk < 2; ++sk) {
+                const bf16x8 pb = pack8(s, sk);
+                const short8v b0 = __builtin_shufflevector(vl[4 * sk + 0], vl[4 * sk + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const short8v b1 = __builtin_shufflevector(vl[4 * sk + 2], vl[4 * sk + 3], 0, 1, 2, 3, 4, 5, 6, 7);
+                if (FIRST && sk == 0) {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), pb, z, 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), pb, z, 0, 0, 0);
+                } else {
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b0), pb, o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b1), pb, o[1], 0, 0, 0);
+                }
             }
         }
-        if (pend) {  // the last tile's second half (its slot is not written again: the tail DMAs re-fetch it in place)
-            short4v vl[8];
-            v_read(pend_slot, vl);
-            sm_exp_pv(std::false_type{}, vl);
-            store_item(pbh, pq0);
+        slot = slot + 1 == R ? 0 : slot + 1;
+    };
+
+    for (int j = 0; j < nmy; ++j) {
+        const bool active = q0 < N;  // wave-uniform
+        tile_step(std::true_type{}, j, 0, active);
+        for (int p = 1; p < nt; ++p) tile_step(std::false_type{}, j, p, active);
+
+        // ---- item finished: ST stores per active wave, never waited for explicitly ----
+        if (active) {
+            const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+            const float inv = __builtin_amdgcn_rcpf(l_tot);  // 1 ulp; the result is rounded to bf16
+            const int b = bh / H, h = bh - b * H;
+            if constexpr (LSE) {
+                if (hi == 0 && q0 + r < N) lse[(size_t)bh * N + q0 + r] = m_run + log2f(l_tot);
+            }
+            {
+                // The lane halves trade 8-byte pieces (v_permlane32_swap) so that every lane holds 8 consecutive head
+                // dims: 16-byte stores, four per item instead of eight, each row's 128 bytes touched by four instructions.
+                // Through a buffer resource over the image's rows of this head: a 32-bit lane offset, rows >= N out of range.
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(out + (size_t)b * N * D + (size_t)h * DH), 0, (unsigned)(N - 1) * (unsigned)(D * 2) + (unsigned)(DH * 2), 0x00020000);
+                const unsigned ooff = (q0 + r < N) ? (unsigned)(q0 + r) * (unsigned)(D * 2) + (unsigned)(16 * hi) : 0x80000000u;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    unsigned w[4][2];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        bf16x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[d][g4 * 4 + e] * inv);
+                        const u32x2 u = __builtin_bit_cast(u32x2, v);
+                        w[g4][0] = u[0];
+                        w[g4][1] = u[1];
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        // lanes < 32 keep piece 2pr and receive their partner's; lanes >= 32 keep piece 2pr+1
+                        u32x4 pk;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(w[2 * pr][k], w[2 * pr + 1][k], false, false);
+                            pk[k] = (unsigned)sw[0];
+                            pk[2 + k] = (unsigned)sw[1];
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, (int)(ooff + (unsigned)(d * 64 + 32 * pr)), 0, 0);
+                    }
+                }
+            }
+        }
+        prev_active = active;
+        if (j + 1 < nmy) {
+            bh = item_bh(j + 1, &qb);
+            q0 = (qb * NW + wave) * 32;
         }
     }
     wait_vm<0>();  // the dummy DMAs of the tail must land before the LDS is released
