@@ -14,10 +14,12 @@
 #include "vit_common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float kDeferLog2 = 6.0f;  // as attention_dh64.hip
 constexpr int NDMA = 8;  // waves of a workgroup that issue the K / V DMA (4 rows each = one 32-key tile); a workgroup has 8..12 waves
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -163,18 +165,16 @@ __global__ __launch_bounds__(NWV * 64) void attention_ring_kernel(const RingSrc 
         for (int s = 0; s < R - 1; ++s) dma_next(s);
     }
 
-    f32x16 o[G::DB];
-#pragma unroll
-    for (int d = 0; d < G::DB; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[G::DB];  // written by the first tile of every item
+    float m_run = 0.f, l_run = 0.f;
 
     int slot = 0, pslot = R - 1;
     bool prev_active = false;
-    for (int j = 0; j < nmy; ++j) {
-        const bool active = q0 < N;  // wave-uniform
-        for (int p = 0; p < nt; ++p) {
+    // One tile step. FIRST (p = 0 of an item): the running max is the tile's own, O and l start from this tile (the PV
+    // products take a zero accumulator, nothing is zeroed or rescaled) -- as in attention_dh64.hip.
+    auto tile_step = [&](auto FIRSTC, int j, int p, bool active) {
+        constexpr bool FIRST = decltype(FIRSTC)::value;
+        {
             // counted wait: this wave's pieces of the current tile have landed. Younger operations that may stay in
             // flight: (R-2)*C tile DMAs; while p <= R-2 also the previous item's ST stores (if the wave had queries in
             // it) and, from p = 1, the NQ loads of the Q prefetch.
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NWV * 64) void attention_ring_kernel(const RingSrc 
                 }
             }
             asm volatile("s_barrier" ::: "memory");
-            if (p == 0) {
+            if constexpr (FIRST) {
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) qf[ks] = *(const bf16x8*)(qslot + kro[ks]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -247,15 +247,22 @@ __global__ __launch_bounds__(NWV * 64) void attention_ring_kernel(const RingSrc 
 #pragma unroll
                 for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
                 mx = max_across_halves(mx);
-                const float m_new = fmaxf(m_run, mx * scale_log2e);
-                if (__any(m_new > m_run)) {
-                    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    m_run = m_new;
-                    l_run *= alpha;
+                if constexpr (FIRST) {
+                    m_run = mx * scale_log2e;
+                } else {
+                    // the running max is left alone until a score outgrows it by more than kDeferLog2 (base 2): P stays
+                    // <= 2^kDeferLog2, and the O / l rescale, which random scores trigger in most tiles (one of a wave's 32
+                    // queries meets a new maximum: 63 % of the tiles even at tile 32 of 1025 tokens), runs only when it must
+                    const float m_new = fmaxf(m_run, mx * scale_log2e);
+                    if (__any(m_new > m_run + kDeferLog2)) {
+                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                        m_run = m_new;
+                        l_run *= alpha;
 #pragma unroll
-                    for (int d = 0; d < G::DB; ++d)
+                        for (int d = 0; d < G::DB; ++d)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+                            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+                    }
                 }
                 float psum = 0.f;
 #pragma unroll
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(NWV * 64) void attention_ring_kernel(const RingSrc 
                     s[e] = __builtin_amdgcn_exp2f(s[e] * scale_log2e - m_run);
                     psum += s[e];
                 }
-                l_run += psum;
+                if constexpr (FIRST) l_run = psum; else l_run += psum;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int sk = 0; sk < 2; ++sk)
@@ -277,17 +284,28 @@ __global__ __launch_bounds__(NWV * 64) void attention_ring_kernel(const RingSrc 
 #pragma unroll
                     for (int d = 0; d < G::DB; ++d) {
                         const short8v both = __builtin_shufflevector(vl[d][sk][0], vl[d][sk][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pb, o[d], 0, 0, 0);
+                        if (FIRST && sk == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pb, z, 0, 0, 0);
+                        } else {
+                            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pb, o[d], 0, 0, 0);
+                        }
                     }
                 }
             }
             slot = slot + 1 == R ? 0 : slot + 1;
         }
+    };
+
+    for (int j = 0; j < nmy; ++j) {
+        const bool active = q0 < N;  // wave-uniform
+        tile_step(std::true_type{}, j, 0, active);
+        for (int p = 1; p < nt; ++p) tile_step(std::false_type{}, j, p, active);
 
         // ---- item finished: ST stores per active wave, never waited for explicitly
         if (active) {
             const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-            const float inv = 1.0f / l_tot;
+            const float inv = __builtin_amdgcn_rcpf(l_tot);  // 1 ulp; the result is rounded to bf16
             const int b = bh / H, h = bh - b * H;
             if constexpr (LSE) {
                 if (hi == 0 && q0 + r < N) lse[(size_t)bh * N + q0 + r] = m_run + log2f(l_tot);
@@ -295,8 +313,10 @@ __global__ __launch_bounds__(NWV * 64) void attention_ring_kernel(const RingSrc 
             {
                 // The lane halves trade 8-byte pieces (v_permlane32_swap) so that every lane holds 8 consecutive head
                 // dims: 16-byte stores (DH % 16 == 0: a pair of pieces is in or out as a whole)
-                bf16_t* op = out + ((size_t)b * N + q0 + r) * D + (size_t)h * DH + 8 * hi;
-                const bool row_ok = q0 + r < N;
+                // through a buffer resource over the image's rows of this head: 32-bit lane offsets, rows >= N out of range
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(out + (size_t)b * N * D + (size_t)h * DH), 0, (unsigned)(N - 1) * (unsigned)(D * 2) + (unsigned)(DH * 2), 0x00020000);
+                const unsigned ooff = (q0 + r < N) ? (unsigned)(q0 + r) * (unsigned)(D * 2) + (unsigned)(16 * hi) : 0x80000000u;
 #pragma unroll
                 for (int d = 0; d < G::DB; ++d) {
                     unsigned w[4][2];
@@ -319,17 +339,11 @@ __global__ __launch_bounds__(NWV * 64) void attention_ring_kernel(const RingSrc 
                                 pk[k] = (unsigned)sw[0];
                                 pk[2 + k] = (unsigned)sw[1];
                             }
-                            if (row_ok) *(u32x4*)(op + d * 32 + 16 * pr) = pk;
+                            __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, (int)(ooff + (unsigned)(d * 64 + 32 * pr)), 0, 0);
                         }
                     }
                 }
             }
-#pragma unroll
-            for (int d = 0; d < G::DB; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-            m_run = -INFINITY;
-            l_run = 0.f;
         }
         prev_active = active;
         if (j + 1 < nmy) {
