@@ -194,7 +194,8 @@ def test_determinism_repeat_runs():
 
 @pytest.mark.gpu
 def test_two_stream_forward_equals_single_stream(monkeypatch):
-    """vit_forward cuts batches >= 64 into two chunks (5 : 3) on two streams (VIT_AMD_STREAMS, read at vit_create).
+    """vit_forward cuts batches whose smaller chunk keeps >= 6304 token rows into two chunks (5 : 3) on two streams
+    (VIT_AMD_STREAMS = 1..4, read at vit_create).
     Images are independent and the kernels deterministic: the outputs must be bit-identical to the
     single-stream run, for an odd batch (uneven halves) and back-to-back calls on the same workspace."""
     import torch
@@ -203,9 +204,10 @@ def test_two_stream_forward_equals_single_stream(monkeypatch):
     from vit_amd.encoder import ViTEncoder
     cfg = ViTConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
     sd = synth.synthetic_state_dict(cfg, seed=0)
-    px = synth.synthetic_images(cfg, 71, seed=1).cuda().to(torch.bfloat16)
+    # 141 images x 197 tokens: two chunks 87 | 54, three of 47, four of 35 -- every chunk above the 6304-row minimum
+    px = synth.synthetic_images(cfg, 141, seed=1).cuda().to(torch.bfloat16)
     outs = []
-    for k in ("1", "2", "3"):
+    for k in ("1", "2", "3", "4"):
         monkeypatch.setenv("VIT_AMD_STREAMS", k)
         enc = ViTEncoder(cfg, dtype=torch.bfloat16, device="cuda:0")
         enc.load_state_dict(sd)

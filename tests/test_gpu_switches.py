@@ -7,6 +7,8 @@ small script in a child process (the child is started BEFORE it touches the GPU;
 * VIT_AMD_ATTN_BWD_FUSED: the one-pass attention backward against the three-launch form it replaces.
 * VIT_AMD_ATTN_RING: head_dim-80 attention on the LDS-DMA ring kernel against the staged kernel it replaces (both
   fp32 online softmax over 32-key tiles; checked to bf16 tolerance, and both against the oracle in test_gpu_kernels).
+* VIT_AMD_RING_WAVES: waves per workgroup of the head_dim-80 ring kernel; VIT_AMD_BWD_SIDE_STREAM: weight gradients beside the
+  data gradients or behind them -- neither may change a bit.
 * VIT_AMD_SPLIT_PCT / VIT_AMD_STREAMS: where vit_forward cuts the batch for its two streams changes which launch a row
   belongs to, never its arithmetic: the encoder output must be bit-identical for every cut and for a single stream.
 """
@@ -101,6 +103,36 @@ torch.save(outs, sys.argv[1])
 print(json.dumps({"ok": all(bool(torch.isfinite(o.float()).all()) for o in outs.values())}))
 """
 
+RING_WAVES_SCRIPT = r"""
+import json, sys, torch
+from vit_amd import ops, synth
+qkv = synth.normal((3, 1025, 3 * 2 * 80), 17, "qkv", std=1.5).to("cuda:0", torch.bfloat16)
+o = ops.attention(qkv, 2)
+torch.save(o.cpu(), sys.argv[1])
+print(json.dumps({"ok": bool(torch.isfinite(o.float()).all())}))
+"""
+
+SIDE_STREAM_SCRIPT = r"""
+import hashlib, json, torch
+from vit_amd import synth
+from vit_amd.config import ViTConfig
+from vit_amd.encoder import ViTEncoder
+from vit_amd.trainer import ViTTrainer
+dev = torch.device("cuda:0")
+cfg = ViTConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, image_size=64, patch_size=8)
+enc = ViTEncoder(cfg, dtype=torch.bfloat16, device=dev)
+enc.load_state_dict(synth.synthetic_state_dict(cfg, seed=0, device=dev))
+tr = ViTTrainer(enc)
+px = synth.synthetic_images(cfg, 128, seed=1, device=dev).to(torch.bfloat16)   # 8320 tokens: the side stream is used
+w = synth.normal((128, cfg.hidden_size), 5, "wp", 0.5, device=dev).to(torch.bfloat16)
+out = tr.forward(px)
+tr.backward(None, w)
+torch.cuda.synchronize()
+h = lambda t: hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+keys = ["layers.0.mlp.fc1.weight", "layers.1.mlp.fc2.weight", "layers.0.attention.q_proj.weight", "layers.1.attention.o_proj.weight"]
+print(json.dumps({k: h(tr.grad(k)) for k in keys}))
+"""
+
 SPLIT_SCRIPT = r"""
 import hashlib, json, torch
 from vit_amd import synth
@@ -181,6 +213,27 @@ def test_one_pass_attention_backward_matches_three_launch_form(tmp_path):
             assert (fj - tj).abs().max().item() <= tj.abs().max().item() / 64, (key, j)
             # both are 0.24 % rms from the fp64 gradient (tools/cmp_attn_bwd.py: bf16 P / dS operands and outputs)
             assert ((fj - tj).double().norm() / tj.double().norm()).item() <= 5e-3, (key, j)
+
+
+def test_ring_attention_wave_counts_agree(tmp_path):
+    """VIT_AMD_RING_WAVES forces the waves per workgroup of the head_dim-80 ring kernel (8..12; the default policy picks
+    12 at 1025 tokens). The wave count only changes which wave owns which 32 queries: same bits for every count."""
+    import torch
+    outs = []
+    for w in ("8", "9", "10", "11", "12", ""):
+        f = str(tmp_path / f"w{w}.pt")
+        assert run_child(RING_WAVES_SCRIPT, {"VIT_AMD_RING_WAVES": w} if w else {}, f)["ok"]
+        outs.append(torch.load(f, weights_only=True))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_backward_side_stream_does_not_change_the_weight_gradients():
+    """VIT_AMD_BWD_SIDE_STREAM=0 runs the weight gradients on the main stream instead of beside the data gradients: the
+    matrices are summed in a fixed order either way, so they must be bit-identical."""
+    on = run_child(SIDE_STREAM_SCRIPT, {})
+    off = run_child(SIDE_STREAM_SCRIPT, {"VIT_AMD_BWD_SIDE_STREAM": "0"})
+    assert len(on) == 4 and on == off
 
 
 def test_stream_split_point_does_not_change_the_bits():
