@@ -206,7 +206,8 @@ int vit_attention_fwd_train(const void* qkv, void* out, float* lse, int batch, i
                             void* stream);
 /* Backward of eager_attention_forward (MV:164-189): dqkv [batch*seq, 3*heads*head_dim] from qkv,
  * the forward output `out`, its gradient `d_out` and `lse`; `delta_scratch` is fp32
- * [batch, heads, seq]. Bitwise reproducible (no atomics). */
+ * [batch, heads, seq] (unused by the one-pass kernel that takes head_dim 64 at 97..224 tokens). Bitwise
+ * reproducible (no atomics). */
 int vit_attention_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, float* delta_scratch,
                       void* dqkv, int batch, int seq, int heads, int head_dim, void* stream);
 
@@ -253,7 +254,9 @@ int vit_forward_train(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, int
  * gradient of last_hidden_state; CLIP contexts also take d_pooled [batch, D] or NULL; ViT contexts
  * fold d_pooled into the CLS rows of d_hidden themselves), stages 1..L = layers L-1..0,
  * stage L+1 = embeddings (needs the pixels). Stage 0 zeroes `grads`. After stage s the gradients
- * written by that stage are final, so the caller may all-reduce them while later stages run. */
+ * written by that stage are final, so the caller may all-reduce them while later stages run.
+ * `stash` must be one that a successful vit_forward_train of THIS context filled, with the same `batch` (and, for
+ * the embedding stage, the same pixel dtype); several stashes may be in flight (micro-batches): VIT_E_INVALID otherwise. */
 int vit_backward_stage(vit_ctx* ctx, int stage, const void* pixels_dev, int pixel_dtype, int batch,
                        const void* d_hidden, const void* d_pooled, const void* stash, void* grads, void* workspace,
                        size_t workspace_bytes, void* stream);
