@@ -624,12 +624,12 @@ inline double single_us(int M, int NT, int nk, int ncu, int mi) {
     const long tiles = (long)ceil_div(M, 64 * mi) * NT;
     return 4.0 + (double)((tiles + ncu - 1) / ncu) * tile_us(mi, nk);
 }
-// Problems of at least kFewTileMaxRows rows keep 256-row tiles: vit_forward runs them as two chunks on two streams, and
-// there the other stream's kernels fill the CUs a partial round leaves idle -- shorter tiles (less work per operand byte)
-// then cost more than they save (same box, planner on / off: ViT-B/16 batch 256 8.70 / 8.48 ms, CLIP-L/14 batch 128
-// 43.2 / 42.6, ViT-H/14 batch 64 82.4 / 80.9; single-stream sizes: CLIP-L/14 batch 16 6.43 / 6.81 ms, ViT-B/16 batch 32
-// 1.87 / 2.14, ViT-H/14 batch 8 12.06 / 12.27).
-constexpr int kFewTileMaxRows = 2 * 32 * 197;  // = 2 x the minimum chunk of vit_num_chunks (vit_capi.hip)
+// Inside a two-chunk vit_forward (GemmExt::concurrent) every launch keeps 256-row tiles: there the other stream's kernels
+// fill the CUs a partial round leaves idle -- shorter tiles (less work per operand byte) then cost more than they save (same
+// box, planner on / off inside the chunks: ViT-B/16 batch 256 8.70 / 8.48 ms, CLIP-L/14 batch 128 43.2 / 42.6, ViT-H/14 batch 64
+// 82.4 / 80.9). A launch that has the chip to itself gains at every size: single-stream sizes CLIP-L/14 batch 16 6.43 / 6.81 ms,
+// ViT-B/16 batch 32 1.87 / 2.14, ViT-H/14 batch 8 12.06 / 12.27; full-batch launches (M = 50,432: a tail of 128- or 192-row
+// tiles behind whole rounds) o_proj + residual 71 / 74 us, fc2 + residual 208 / 216, VIT_AMD_STREAMS=1 forward 8.86 / 8.92 ms.
 inline RowPlan plan_rows(int M, int N, int K, int ncu, bool allow) {
     // lab switch VIT_AMD_GEMM_MI: 4 = 256-row tiles only (the kernel of rounds 1-2), 3 / 2 = that height everywhere
     static const int forced = getenv("VIT_AMD_GEMM_MI") ? atoi(getenv("VIT_AMD_GEMM_MI")) : 0;
@@ -638,7 +638,7 @@ inline RowPlan plan_rows(int M, int N, int K, int ncu, bool allow) {
         best.mi[0] = forced;
         return best;
     }
-    if (!allow || M >= kFewTileMaxRows) return best;
+    if (!allow) return best;
     const int NT = ceil_div(N, BN), nk = K / BK;
     double best_us = single_us(M, NT, nk, ncu, 4);
     auto best_single = [&](int rows, int* mi_out) {
