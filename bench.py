@@ -400,7 +400,11 @@ def main():
             line["roofline"] = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
                                 "frac": r["frac"],
                                 "traffic": pmc_traffic_bytes(dom) if (args.config == "b16" and local_batch == LOCAL_BATCH) else None,
-                                "kernel": "bf16 MFMA GEMM (" + dom + ")", "us_per_launch": r["us_per_launch"]}
+                                "kernel": "bf16 MFMA GEMM (" + dom + ")", "us_per_launch": r["us_per_launch"],
+                                # one operator call of the full batch: the few-tile planner runs it as a head of whole
+                                # 256-row-tile rounds plus a tail of shorter tiles (template instances <..., 4> and
+                                # <..., 3|2> of gemm8p_persist_kernel; their rocprof averages add up to this figure)
+                                "launch": "one GEMM call = head + tail launch of gemm8p_persist_kernel (DESIGN 11.1)"}
             line["kernels"] = ks
         if world == 1 and args.config == "b16" and not args.no_other_configs:
             enc.close()

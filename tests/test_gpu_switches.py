@@ -64,7 +64,7 @@ from vit_amd import ops, synth
 dev = "cuda:0"
 out = {}
 h = lambda t: hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
-# few-tile shapes (M < 12608 rows): the planner picks 192-row tiles (M = 9232, N = 1024: 196 tiles in one round), a
+# few-tile shapes: the planner picks 192-row tiles (M = 9232, N = 1024: 196 tiles in one round), a
 # head of 256-row tiles plus a shorter tail, or 128-row tiles, by shape; ragged M and N
 for (m, n, k) in [(9232, 1024, 1024), (9232, 3072, 1024), (6304, 768, 2048), (4616, 4096, 1024), (5001, 1000, 256)]:
     x = (synth.normal((m, k), 3, "x") * 1.5 + 0.3).to(dev, torch.bfloat16)

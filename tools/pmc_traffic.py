@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --output-format csv) of
 `VIT_AMD_STREAMS=1 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernels` into the per-launch
-averages bench.py reads (profiles/r02d_traffic.json).
+averages bench.py reads (the newest profiles/r*_traffic.json).
 
-  python tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/r02d_traffic.json
+  python tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/r03b_traffic.json
 
 Only library kernels are kept, grouped by the bench's kernel names; launches of the same kernel on other shapes
-(the pooled-row LayerNorm) are dropped by their grid size."""
+(the pooled-row LayerNorm) are dropped by their grid size. The figures are per operator CALL: the few-tile planner
+may run one GEMM as two launches (a head of 256-row tiles, then a tail of shorter tiles: two template instances of
+the same kernel), whose counters are added; `launches_per_call` says how many."""
 import csv, glob, json, os, sys
 
 GROUPS = [  # bench name, substring of the kernel name
@@ -33,11 +35,13 @@ def per_kernel(dirname, counter):
             if sub in name:
                 if key == "layernorm" and int(row["Grid_Size"]) < 256 * 256:
                     break  # pooled rows only
-                a = acc.setdefault(key, [name, 0.0, 0])
+                a = acc.setdefault(key, [name, 0.0, {}])
                 a[1] += float(row["Counter_Value"])
-                a[2] += 1
+                a[2][name] = a[2].get(name, 0) + 1
                 break
-    return {k: (v[0], v[1] / v[2], v[2]) for k, v in acc.items()}
+    # calls = launches of the most frequent template instance (every call launches it once; a planned call adds a
+    # second instance for its tail)
+    return {k: (v[0], v[1] / max(v[2].values()), max(v[2].values()), sum(v[2].values())) for k, v in acc.items()}
 
 
 def main():
@@ -53,7 +57,8 @@ def main():
     }
     for key, _ in GROUPS:
         if key in fetch and key in write:
-            out["per_launch_kb"][key] = {"kernel": fetch[key][0][:120], "launches": fetch[key][2],
+            out["per_launch_kb"][key] = {"kernel": fetch[key][0][:120], "calls": fetch[key][2],
+                                         "launches_per_call": round(fetch[key][3] / fetch[key][2], 2),
                                          "FETCH_SIZE": round(fetch[key][1], 1), "WRITE_SIZE": round(write[key][1], 1)}
     json.dump(out, sys.stdout, indent=2)
     print()
