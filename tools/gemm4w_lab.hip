@@ -64,7 +64,9 @@ struct Frag {
     bf16x8 f[4][2];  // [16-row block][k-step of 32]
 };
 
-// VAR (lab only, timing-only builds): bit0 no DMA in the phases, bit1 no barrier, bit2 no LDS reads, bit3 no MFMA
+// VAR (lab only, timing-only builds): bit0 no DMA in the phases, bit1 no barrier, bit2 no LDS reads, bit3 no MFMA,
+// bit4 (A) / bit5 (W) operand panels addressed as if K-tile-packed ([K-tile][256 rows][128 B] inside each 256-row panel: same bytes, same
+// panel, contiguous 32 KiB per K-tile instead of 256 pieces of 128 B at the row stride)
 template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm4w_kernel(const Params P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -102,12 +104,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                 const int rr = r & 63;
                 int ar = (r >> 6) * 128 + u * 64 + rr;
                 if (m0 + ar > P.M - 1) ar = P.M - 1 - m0;
-                unsigned ta = (unsigned)ar * lda2;   // kept apart from the add: fused into a 64-bit mad the offset lives in a register PAIR
+                unsigned ta = (unsigned)ar * ((VAR & 16) ? 128u : lda2);   // kept apart from the add: fused into a 64-bit mad the offset lives in a register PAIR
                 asm volatile("" : "+v"(ta));
                 a_of[u][j] = ta + ch;
                 int wrow = (r >> 6) * 128 + (rr & 15) * 8 + u * 4 + (rr >> 4);
                 if (n0 + wrow > P.N - 1) wrow = P.N - 1 - n0;
-                unsigned tw = (unsigned)wrow * lda2;
+                unsigned tw = (unsigned)wrow * ((VAR & 32) ? 128u : lda2);
                 asm volatile("" : "+v"(tw));
                 w_of[u][j] = tw + ch;
             }
@@ -121,20 +123,20 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         constexpr int TYPE = decltype(TYPEC)::value;
         constexpr int u = (TYPE == 0 || TYPE == 1) ? 0 : 1;
         unsigned char* d = dma_base + slot * UNIT;
-        const int ko = kt * (BK * 2);
+        const int koa = kt * ((VAR & 16) ? 256 * 128 : BK * 2), kow = kt * ((VAR & 32) ? 256 * 128 : BK * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (TYPE == 0 || TYPE == 3) bufdma16(Ar, a_of[u][j], ko, d + j * 1024);
-            else bufdma16(Wr, w_of[u][j], ko, d + j * 1024);
+            if constexpr (TYPE == 0 || TYPE == 3) bufdma16(Ar, a_of[u][j], koa, d + j * 1024);
+            else bufdma16(Wr, w_of[u][j], kow, d + j * 1024);
         }
     };
     auto stage1 = [&](auto TYPEC, int slot, int kt, auto JC) __attribute__((always_inline)) {
         constexpr int TYPE = decltype(TYPEC)::value, j = decltype(JC)::value;
         constexpr int u = (TYPE == 0 || TYPE == 1) ? 0 : 1;
         unsigned char* d = dma_base + slot * UNIT;
-        const int ko = kt * (BK * 2);
-        if constexpr (TYPE == 0 || TYPE == 3) bufdma16(Ar, a_of[u][j], ko, d + j * 1024);
-        else bufdma16(Wr, w_of[u][j], ko, d + j * 1024);
+        const int koa = kt * ((VAR & 16) ? 256 * 128 : BK * 2), kow = kt * ((VAR & 32) ? 256 * 128 : BK * 2);
+        if constexpr (TYPE == 0 || TYPE == 3) bufdma16(Ar, a_of[u][j], koa, d + j * 1024);
+        else bufdma16(Wr, w_of[u][j], kow, d + j * 1024);
     };
 
     // ---- read side
@@ -298,22 +300,27 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        v[c] = acc[ha][mi][c >> 2][c & 3] + bias[c];
+                        if constexpr (EPI == VIT_EPI_GELU) {  // the packed polynomial on row pairs (adjacent registers)
+                            f32x2 a{v[c][0], v[c][1]}, b{v[c][2], v[c][3]};
+                            act_gelu_pk2(a, b);
+                            v[c] = f32x4{a.x, a.y, b.x, b.y};
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const unsigned voff = voff0 + (unsigned)((ha * 64 + mi * 16 + j) * P.N) * 2u;
                         bf16x8 ov;
 #pragma unroll
-                        for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                            for (int ni = 0; ni < 4; ++ni) {
-                                float v = acc[ha][mi][hb][ni][j] + bias[hb * 4 + ni];
-                                v = apply_act_bf16<EPI>(v);
-                                ov[hb * 4 + ni] = (bf16_t)v;
-                            }
+                        for (int c = 0; c < 8; ++c) ov[c] = (bf16_t)v[c][j];
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), Cr, (int)voff, 0, 0);
                         G4_SB();
                     }
+                }
         }
         if (!has_next) break;
         lt = nlt;
@@ -368,6 +375,10 @@ int launch_gemm_bf16_4w(const void* A, const void* W, const float* bias, const v
         case 6: return g4::launch<VIT_EPI_BIAS, 6>(P, ncu, stream);
         case 7: return g4::launch<VIT_EPI_BIAS, 7>(P, ncu, stream);
         case 5: return g4::launch<VIT_EPI_BIAS, 5>(P, ncu, stream);
+        case 16: return g4::launch<VIT_EPI_BIAS, 16>(P, ncu, stream);
+        case 32: return epi == VIT_EPI_GELU ? g4::launch<VIT_EPI_GELU, 32>(P, ncu, stream) : g4::launch<VIT_EPI_BIAS, 32>(P, ncu, stream);
+        case 48: return g4::launch<VIT_EPI_BIAS, 48>(P, ncu, stream);
+        case 56: return g4::launch<VIT_EPI_BIAS, 56>(P, ncu, stream);
     }
 #endif
     switch (epi) {

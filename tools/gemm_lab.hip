@@ -203,9 +203,12 @@ int main(int argc, char** argv) {
         if (sh.epi == VIT_EPI_BIAS || sh.epi == VIT_EPI_GELU) {
             vars.push_back({"g4w", [&](bf16_t* C) { launch_gemm_bf16_4w(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); }});
             vars.push_back({"ns4w", [&](bf16_t* C) { g4_dbg = 1; launch_gemm_bf16_4w(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); g4_dbg = 0; }});
+            if (sh.epi == VIT_EPI_GELU)
+                vars.push_back({"4w_pkW", [&](bf16_t* C) { g4_dbg = 32 << 1; launch_gemm_bf16_4w(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); g4_dbg = 0; }});
             if (sh.epi == VIT_EPI_BIAS)
-                for (int v : {1, 2, 3, 4, 5, 6, 7, 8}) {
-                    static const char* nm[] = {"", "4w_nodma", "4w_nobar", "4w_nodmabar", "4w_nords", "4w_nodma_rds", "4w_nords_bar", "4w_mfmaonly", "4w_nomfma"};
+                for (int v : {1, 2, 3, 4, 5, 6, 7, 8, 16, 32, 48, 56}) {
+                    static const char* nm[57] = {"", "4w_nodma", "4w_nobar", "4w_nodmabar", "4w_nords", "4w_nodma_rds", "4w_nords_bar", "4w_mfmaonly", "4w_nomfma"};
+                    nm[16] = "4w_pkA"; nm[32] = "4w_pkW"; nm[48] = "4w_pkAW"; nm[56] = "4w_pkAW_nomfma";
                     vars.push_back({nm[v], [&, v](bf16_t* C) { g4_dbg = 1 | (v << 1); launch_gemm_bf16_4w(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); g4_dbg = 0; }});
                 }
         }
