@@ -56,6 +56,7 @@ struct Params {
     const float* bias;
     bf16_t* C;
     int M, N, K, lda;
+    int ldw;     // row pitch of W (elements); lab: may differ from lda (timing-only variants read a W allocated with slack)
     int NT, T;   // tiles along N, tiles in all
     int dbg;     // lab: bit0 = no output stores
 };
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int mt = tile_idx / P.NT, nt = tile_idx - mt * P.NT;
         const int m0 = mt * BM, n0 = nt * BN;
         int lane_v = lane;
-        const unsigned lda2 = (unsigned)P.lda * 2u;
+        const unsigned lda2 = (unsigned)P.lda * 2u, ldw2 = (unsigned)P.ldw * 2u;
         asm volatile("" : "+v"(lane_v));  // recomputed here, once per tile: hoisted out of the loop these values only get spilled
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -109,13 +110,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, 1))
                 a_of[u][j] = ta + ch;
                 int wrow = (r >> 6) * 128 + (rr & 15) * 8 + u * 4 + (rr >> 4);
                 if (n0 + wrow > P.N - 1) wrow = P.N - 1 - n0;
-                unsigned tw = (unsigned)wrow * ((VAR & 32) ? 128u : lda2);
+                unsigned tw = (unsigned)wrow * ((VAR & 32) ? 128u : ldw2);
                 asm volatile("" : "+v"(tw));
                 w_of[u][j] = tw + ch;
             }
         const unsigned span = (unsigned)BM * (unsigned)P.lda * 2u;
         Ar = __builtin_amdgcn_make_buffer_rsrc((void*)(P.A + (size_t)m0 * P.lda), 0, span, 0x00020000);
-        Wr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * P.lda), 0, span, 0x00020000);
+        Wr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.W + (size_t)n0 * P.ldw), 0, (unsigned)BN * ldw2, 0x00020000);
     };
     unsigned char* const dma_base = smem + wave * 4096;
     // TYPE 0: A0, 1: B0, 2: B1, 3: A1
@@ -359,14 +360,19 @@ int launch_gemm_bf16_4w(const void* A, const void* W, const float* bias, const v
     }
     g4::Params P{};
     P.A = (const bf16_t*)A; P.W = (const bf16_t*)W; P.bias = bias; P.C = (bf16_t*)C;
-    P.M = M; P.N = N; P.K = K; P.lda = K;
+    P.M = M; P.N = N; P.K = K; P.lda = K; P.ldw = K;
+#ifdef G8_LAB
+    if (g4_dbg & (1 << 20)) P.ldw = K + 64;
+    if (g4_dbg & (1 << 21)) P.ldw = K + 8;
+    if (g4_dbg & (1 << 22)) P.ldw = K + 32;
+#endif
     P.NT = ceil_div(N, g4::BN);
     P.T = ceil_div(M, g4::BM) * P.NT;
 #ifdef G8_LAB
     P.dbg = g4_dbg;
 #endif
 #ifdef G8_LAB
-    switch (g4_dbg >> 1) {
+    switch ((g4_dbg >> 1) & 0xFF) {
         case 1: return g4::launch<VIT_EPI_BIAS, 1>(P, ncu, stream);
         case 2: return g4::launch<VIT_EPI_BIAS, 2>(P, ncu, stream);
         case 3: return g4::launch<VIT_EPI_BIAS, 3>(P, ncu, stream);
