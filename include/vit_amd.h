@@ -188,6 +188,19 @@ int vit_layernorm_fold(const void* weight, const float* gamma, const float* beta
 int vit_gemm_ln_folded(const void* x, const void* weight_folded, const float* bias_folded, const float* colsum,
                        const float* stats, void* C, int M, int N, int K, int epilogue, void* stream);
 
+/* ---- The statistics of the NEXT folded LayerNorm from the residual GEMM that writes its input (bf16). In vit_forward
+ * the o_proj and fc2 GEMMs (MV:236 + :277, MV:252 + :284) write the rows that LN2 / the next layer's LN1 (MV:281, :274)
+ * normalise; their epilogue also leaves, per 64-column group g and row r, the pair (sum, sum of squares) of the bf16 values
+ * it stored: row_part[(g * M + r) * 2 .. + 1], N / 64 slabs of M pairs. vit_row_stats_finalize adds the slabs left to right
+ * and writes stats[r] = (mean * rstd, rstd) -- bit for bit what vit_layernorm_stats computes from the stored rows (both
+ * run one instruction sequence, csrc/vit_common.h row16_stats), so whether a forward took this route (big batches) or the
+ * stand-alone pass (small ones, VIT_AMD_ROW_STATS=0) cannot be seen in its output. Exposed for parity tests and timing.
+ *  vit_gemm_residual_row_stats: C = A W^T + bias + residual as vit_gemm_bias_act(VIT_EPI_RESIDUAL), plus row_part; only
+ *    shapes the persistent kernel takes (N % 64 == 0, K % 128 == 0, K >= 256, M * N >= 4 Mi), VIT_E_INVALID otherwise. */
+int vit_gemm_residual_row_stats(const void* A, const void* W, const float* bias, const void* residual, void* C,
+                                float* row_part, int M, int N, int K, void* stream);
+int vit_row_stats_finalize(const float* row_part, float* stats, int rows, int dim, float eps, void* stream);
+
 /* ---- training-step kernels (VIT_BF16 activations, fp32 statistics and parameter gradients).
  * The reference has no training code at all; these are the backward
  * counterparts of the entry points above, needed by BASELINE.json configs[4]. ---- */

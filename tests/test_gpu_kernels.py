@@ -317,6 +317,53 @@ def test_layer_norm_stats_and_folded_gemm_are_row_position_independent():
     assert torch.equal(ops.linear_ln_folded(x[perm].contiguous(), folded, st[perm].contiguous()), out[perm])
 
 
+@pytest.mark.parametrize("m,n,k", [(5600, 768, 768), (5555, 768, 3072), (9232, 1024, 1024), (4616, 1024, 4096),
+                                   (6000, 1280, 256), (25216, 768, 768), (50432, 768, 3072)])
+def test_residual_gemm_row_sums_give_the_statistics_pass_bit_for_bit(m, n, k):
+    """vit_gemm_residual_row_stats + vit_row_stats_finalize: the residual epilogue of the persistent GEMM leaves per-64-column
+    (sum, sum of squares) of the rows it stores (every tile height of the few-tile planner, head / tail launches, ragged M),
+    and the finalised (mean * rstd, rstd) are the SAME BITS vit_layernorm_stats computes from the stored rows -- so a forward
+    may take either route. The output itself is the plain residual GEMM's, and the sums agree with torch on the stored values."""
+    eps = 1e-6
+    x = (rnd((m, k), "rs.x") * 1.5 + 0.2).to(DEV, torch.bfloat16)
+    w = rnd((n, k), "rs.w", 0.03).to(DEV, torch.bfloat16)
+    b = rnd((n,), "rs.b", 0.2).to(DEV)
+    r = (rnd((m, n), "rs.r") * 2 + 0.4).to(DEV, torch.bfloat16)
+    out, stats, part = ops.linear_residual_row_stats(x, w, b, r, eps)
+    assert torch.equal(out, ops.linear(x, w, b, residual=r))
+    assert torch.equal(stats, ops.layer_norm_stats(out, eps))
+    o = out.double().view(m, n // 64, 64)
+    assert rel_err(part[:, :, 0].t(), o.sum(-1)) < 1e-6
+    assert rel_err(part[:, :, 1].t(), (o * o).sum(-1)) < 1e-6
+    o = out.double()
+    rstd = 1.0 / torch.sqrt(o.var(-1, unbiased=False) + eps)
+    assert rel_err(stats[:, 1], rstd) < 1e-5
+    assert rel_err(stats[:, 0], o.mean(-1) * rstd) < 1e-5
+    out2, stats2, _ = ops.linear_residual_row_stats(x, w, b, r, eps)
+    assert torch.equal(out2, out) and torch.equal(stats2, stats)  # repeatable
+
+
+def test_one_pass_statistics_error_bound_with_a_large_mean():
+    """The one-pass form (var = E[x^2] - mean^2 in fp32) loses accuracy as |mean| / std grows: about 2^-23 (1 + mean^2 / var)
+    sqrt(dim) relative in var. Pinned here at |mean| = 20 std (far beyond what a residual stream shows): rstd within 1e-3,
+    i.e. still below the bf16 rounding of the normalised values; at |mean| <= std it is 1e-6."""
+    for shift, tol in ((0.5, 2e-6), (20.0, 1e-3)):
+        x = (rnd((2048, 768), "lm.x") + shift).to(DEV, torch.bfloat16)
+        st = ops.layer_norm_stats(x, 1e-6).double()
+        xd = x.double()
+        rstd = 1.0 / torch.sqrt(xd.var(-1, unbiased=False) + 1e-6)
+        assert rel_err(st[:, 1], rstd) < tol, shift
+        assert rel_err(st[:, 0], xd.mean(-1) * rstd) < tol, shift
+
+
+def test_residual_row_stats_rejects_shapes_the_persistent_kernel_does_not_take():
+    x = rnd((512, 256), "rj.x").to(DEV, torch.bfloat16)
+    w = rnd((768, 256), "rj.w", 0.03).to(DEV, torch.bfloat16)
+    r = rnd((512, 768), "rj.r").to(DEV, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="persistent kernel"):
+        ops.linear_residual_row_stats(x, w, None, r, 1e-6)
+
+
 def _all_bf16_values(lo, hi, count):
     """every finite bf16 value in [lo, hi], tiled to `count` entries (the GEMM below passes them through unchanged)"""
     bits = torch.arange(0, 1 << 16, dtype=torch.int32).to(torch.int16)

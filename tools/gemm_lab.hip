@@ -217,6 +217,16 @@ int main(int argc, char** argv) {
                     vars.push_back({nm[v], [&, v](bf16_t* C) { g4_dbg = (v >= 16 && v != 56 ? 0 : 1) | (v << 1); launch_gemm_bf16_4w(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); g4_dbg = 0; }});
                 }
         }
+        // residual epilogue that also writes the row sums for the next LayerNorm (GemmExt::row_part); same C bits
+        static float* rpart = nullptr;
+        if (!rpart) hipMalloc(&rpart, (size_t)60000 * 8 * 64);
+        if (sh.epi == VIT_EPI_RESIDUAL && sh.N % 64 == 0)
+            vars.push_back({"8p_rst", [&](bf16_t* C) {
+                GemmExt e{}; e.row_part = rpart;
+                launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, &e, st); }});
+        // the shipped kernel once more, behind the variant above: the order of the variants inside a round is fixed, and a variant
+        // that follows ten launches of a heavier one starts on a chip that has already lowered its clock
+        vars.push_back({"g8p_again", [&](bf16_t* C) { launch_gemm_bf16_8p(A, W, B, R, C, sh.M, sh.N, sh.K, sh.epi, nullptr, st); }});  // (kept as the check of the harness itself)
         // folded-LayerNorm epilogue (GemmExt::ln_stats): bias / activation shapes only; the statistics are arbitrary
         // numbers (timing), so this variant is reported as a mismatch against "shipped"
         static float *lnst = nullptr, *lnc = nullptr;
@@ -248,9 +258,14 @@ int main(int argc, char** argv) {
         const int iters = 10;
         std::vector<std::vector<float>> ms(vars.size());
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        // The chip lowers its clock within a millisecond or two of sustained matrix load, so a variant that follows ten
+        // launches of a lighter kernel (the generic "shipped" one) is timed on a faster chip than the variant behind it: the
+        // same kernel measured 195.5 us in second place and 203.5 us in fourth (fc2 + residual, round 3). Every block
+        // therefore starts with ten untimed launches of its own variant, and the order rotates from round to round.
         for (int r = 0; r < rounds; ++r)
-            for (size_t v = 0; v < vars.size(); ++v) {
-                vars[v].run(C1);
+            for (size_t vv = 0; vv < vars.size(); ++vv) {
+                const size_t v = (vv + (size_t)r) % vars.size();
+                for (int it = 0; it < iters; ++it) vars[v].run(C1);
                 hipEventRecord(e0, st);
                 for (int it = 0; it < iters; ++it) vars[v].run(C1);
                 hipEventRecord(e1, st); hipEventSynchronize(e1);

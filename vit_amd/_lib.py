@@ -69,6 +69,9 @@ SIGNATURES = {
                                    c_void_p]),
     "vit_gemm_ln_folded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p]),
+    "vit_gemm_residual_row_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                            c_void_p]),
+    "vit_row_stats_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "vit_gemm_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_void_p]),
     "vit_attention_fwd_train": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

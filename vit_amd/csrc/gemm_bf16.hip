@@ -370,12 +370,19 @@ int launch_gemm_bf16(const void* A, const void* W, const float* bias, const void
     const int splits = (ext && ext->split_k > 1) ? ext->split_k : 1;
     if (patch == nullptr && gemm_bf16_8p_eligible(M, N, K) && (long)M * N * splits >= 64L * 256 * 256)
         return launch_gemm_bf16_8p(A, W, bias, res, C, M, N, K, epi, ext, stream);
+    VIT_REQUIRE(!(ext && ext->row_part), "gemm: row statistics requested for a shape the persistent kernel does not take (ask gemm_writes_row_stats first)");
     // patch embedding with whole-pixel-row K-tiles (P = 16, 32): persistent kernel with the pixel loader
     if (patch != nullptr && ext == nullptr && epi == VIT_EPI_BIAS && pos != nullptr && K == patch->kreal &&
         gemm_bf16_8p_patch_eligible(M, N, patch) && (long)M * N >= 64L * 256 * 256)
         return launch_gemm_bf16_8p_patch(A, W, bias, pos, C, M, N, patch, stream);
     VIT_REQUIRE(splits == 1, "gemm: split-K requested for a shape the persistent kernel does not take");
     return launch_gemm_bf16_generic(A, W, bias, res, C, M, N, K, epi, patch, pos, stream, ext);
+}
+
+// true when a bf16 residual GEMM of this shape goes to the persistent kernel and can leave the row sums of its output
+// (GemmExt::row_part) -- the same test as the dispatch above
+bool gemm_writes_row_stats(int M, int N, int K) {
+    return N % 64 == 0 && gemm_bf16_8p_eligible(M, N, K) && (long)M * N >= 64L * 256 * 256;
 }
 
 int launch_gemm_bf16_generic(const void* A, const void* W, const float* bias, const void* res, void* C, int M, int N,

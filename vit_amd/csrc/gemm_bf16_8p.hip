@@ -109,6 +109,10 @@ struct PParams {
     // LNF (template flag): LayerNorm folded in -- epilogue value = rstd * acc - (mean * rstd) * ln_c + bias
     const float* ln_stats;   // [M][2] = (mean * rstd, rstd)
     const float* ln_c;       // [N]
+    // RST (template flag) on the residual epilogue (N % 64 == 0): row sums of the stored bf16 output, one slab per 64-column group:
+    // row_part[(col / 64) * part_pitch + row] = (sum x, sum x^2) over those 64 columns (see row_stats_finalize_kernel)
+    float* row_part;
+    long part_pitch;         // rows of one slab (the whole launch's M, also for a row segment of the few-tile planner)
     // EPI_PATCH only: A is the pixel tensor [B, C, image, image]; GEMM row g = b * np + py * grid + px
     const float* pos;        // position table fp32 [np + 1, N]
     int np, grid, patch, image;
@@ -129,8 +133,9 @@ constexpr int EPI_PATCH_DENSE = 101;  // the same epilogue on a dense A (rows = 
 // DMA lanes of the other rows are out of range and move nothing), a wave owns 16 MI of them, and a phase has 4 MI MFMAs.
 // Everything else -- schedule, waits, LDS image, k order -- is the same, so an output element gets the SAME BITS whatever
 // MI computed it: the tile height is a pure speed choice, like the tile order.
-template <int EPI, int OUTM, bool LNF = false, int MI = 4>
+template <int EPI, int OUTM, bool LNF = false, int MI = 4, bool RST = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PParams P) {
+    static_assert(!RST || (EPI == VIT_EPI_RESIDUAL && OUTM == 0 && !LNF), "row sums ride on the bf16 residual epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(MI >= 2 && MI <= 4, "tile height 128 / 192 / 256");
     static_assert(MI == 4 || (EPI != EPI_PATCH && EPI != EPI_PATCH_DENSE), "the patch epilogues assume 256-row tiles");
@@ -446,6 +451,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
             if constexpr (OUTM == 2)
                 Pr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.Cpre + (size_t)m0 * P.N), 0, span, 0x00020000);
             const unsigned voff0 = col_ok ? (unsigned)((wr * WRR + 4 * q) * P.N + nb) * 2u : 0x80000000u;
+            // RST: this wave's 64-column group of the tile has its own slab of (sum, sum of squares) pairs; lane i == 0 of every
+            // 16-lane row stores, the other lanes (and rows >= M) are out of range
+            __amdgpu_buffer_rsrc_t Tr = Cr;
+            unsigned toff0 = 0x80000000u;
+            if constexpr (RST) {
+                Tr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.row_part + ((size_t)(nt * 4 + wc) * P.part_pitch + m0) * 2), 0,
+                                                       (unsigned)rows_here * 8u, 0x00020000);
+                if (i == 0 && col_ok) toff0 = (unsigned)((wr * WRR + 4 * q) * 8);
+            }
             // bias, ln_c (column sums of the folded weight) and the tile's (mean * rstd, rstd) are in LDS behind the ring
             // (DMA of the last K-tile), read by inline asm (a C++ LDS load behind an LDS-DMA draws a vmcnt(0)). The
             // statistics are read two rows at a time, two reads ahead of their use (all 32 rows' pairs up front held 64
@@ -561,6 +575,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm8p_persist_kernel(const PPara
 #pragma unroll
                             for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)v[e];
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), Cr, (int)voff, 0, G8_STORE_AUX);
+                            if constexpr (RST) {
+                                // sums of the STORED values (what the next LayerNorm reads)
+                                const u32x2 du = __builtin_bit_cast(u32x2, ov);
+                                float sm, sq;
+                                row16_stats(du.x, du.y, sm, sq);
+                                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, sm), __builtin_bit_cast(unsigned, sq)}, Tr,
+                                                                      (int)(toff0 + (unsigned)((ha * HR + mi * 16 + j) * 8)), 0, 0);
+                            }
                         }
                         if constexpr (USES_RES) {
                             const int sn = (ha * MI + mi) * 4 + j + RW;
@@ -592,9 +614,9 @@ inline int group_cols(int NT, int K) {
     return (NT + groups - 1) / groups;
 }
 
-template <int EPI, int OUTM, bool LNF = false, int MI = 4>
+template <int EPI, int OUTM, bool LNF = false, int MI = 4, bool RST = false>
 int launch_persist(const PParams& P, int ncu, hipStream_t stream) {
-    auto kern = gemm8p_persist_kernel<EPI, OUTM, LNF, MI>;
+    auto kern = gemm8p_persist_kernel<EPI, OUTM, LNF, MI, RST>;
     static PerDeviceInt attr_set;  // per instantiation and device
     std::atomic<int>* as = attr_set.slot();
     if (!as || !as->load(std::memory_order_relaxed)) {
@@ -670,7 +692,7 @@ inline RowPlan plan_rows(int M, int N, int K, int ncu, bool allow) {
 
 // inference-forward epilogues exist in all three tile heights; everything else is 256-row only.
 // Runs the row plan: segment s covers rows [row0, row0 + rows) of A, C, the residual and the LayerNorm statistics.
-template <int EPI, bool LNF>
+template <int EPI, bool LNF, bool RST = false>
 int launch_persist_planned(const PParams& P0, int ncu, bool allow, hipStream_t stream) {
     const RowPlan plan = plan_rows(P0.M, P0.N, P0.K, ncu, allow);
     int row0 = 0;
@@ -682,13 +704,14 @@ int launch_persist_planned(const PParams& P0, int ncu, bool allow, hipStream_t s
         P.C = P0.C + (size_t)row0 * P0.N;
         if (P0.res) P.res = P0.res + (size_t)row0 * P0.N;
         if (P0.ln_stats) P.ln_stats = P0.ln_stats + (size_t)row0 * 2;
+        if (P0.row_part) P.row_part = P0.row_part + (size_t)row0 * 2;
         P.MT = ceil_div(P.M, 64 * mi);
         P.TMN = P.MT * P.NT;
         P.T = P.TMN;
         int rc;
-        if (mi == 3) rc = launch_persist<EPI, 0, LNF, 3>(P, ncu, stream);
-        else if (mi == 2) rc = launch_persist<EPI, 0, LNF, 2>(P, ncu, stream);
-        else rc = launch_persist<EPI, 0, LNF, 4>(P, ncu, stream);
+        if (mi == 3) rc = launch_persist<EPI, 0, LNF, 3, RST>(P, ncu, stream);
+        else if (mi == 2) rc = launch_persist<EPI, 0, LNF, 2, RST>(P, ncu, stream);
+        else rc = launch_persist<EPI, 0, LNF, 4, RST>(P, ncu, stream);
         if (rc != VIT_OK) return rc;
         row0 += plan.rows[sgm];
     }
@@ -756,7 +779,13 @@ int launch_gemm_bf16_8p(const void* A, const void* W, const float* bias, const v
         case VIT_EPI_BIAS: return g8::launch_persist<VIT_EPI_BIAS, 0>(P, ncu, stream);
         case VIT_EPI_GELU: return pre ? g8::launch_persist<VIT_EPI_GELU, 2>(P, ncu, stream) : g8::launch_persist<VIT_EPI_GELU, 0>(P, ncu, stream);
         case VIT_EPI_QUICK_GELU: return pre ? g8::launch_persist<VIT_EPI_QUICK_GELU, 2>(P, ncu, stream) : g8::launch_persist<VIT_EPI_QUICK_GELU, 0>(P, ncu, stream);
-        case VIT_EPI_RESIDUAL: return g8::launch_persist_planned<VIT_EPI_RESIDUAL, false>(P, ncu, few_ok, stream);
+        case VIT_EPI_RESIDUAL:
+            if (ext && ext->row_part) {
+                VIT_REQUIRE(N % 64 == 0, "gemm8p: row statistics need N %% 64 == 0 (N=%d)", N);
+                P.row_part = ext->row_part; P.part_pitch = M;
+                return g8::launch_persist_planned<VIT_EPI_RESIDUAL, false, true>(P, ncu, few_ok, stream);
+            }
+            return g8::launch_persist_planned<VIT_EPI_RESIDUAL, false>(P, ncu, few_ok, stream);
         case VIT_EPI_DGELU: return g8::launch_persist<VIT_EPI_DGELU, 0>(P, ncu, stream);
         case VIT_EPI_DQUICK_GELU: return g8::launch_persist<VIT_EPI_DQUICK_GELU, 0>(P, ncu, stream);
     }

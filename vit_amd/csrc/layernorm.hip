@@ -5,6 +5,7 @@
 // mean and centred variance by two in-register passes + a 64-lane butterfly reduction.
 // Also the small elementwise kernels of the path (dtype convert, CLS rows).
 #include "vit_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -146,6 +147,77 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const bf16_t* __restrict_
         const int row = row0 + 2 * r + half;
         if (hl == 0 && row < rows) stats[row] = make_float2(mean * rstd, rstd);
     }
+}
+
+// The same statistics in ONE pass, for dim % 64 == 0 (every ViT width): the arithmetic of the residual epilogue of the
+// persistent GEMM (row16_stats, vit_common.h), so that a row gets the same (mean * rstd, rstd) whichever of the two produced
+// them. A 16-lane DPP row takes one row at a time: per 64-column group 4 stored values per lane, the group's (sum, sum of
+// squares) from row16_stats, the groups added left to right, ln_from_sums at the end; lane 0 of the row holds the result.
+// A wave handles 4 * RW rows, all of a row's loads issued before the first use (8 bytes per lane and group).
+template <int NG, int RW>
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, float2* __restrict__ stats, int rows,
+                                                        int64_t xs, float inv_d, float eps) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row0 = wave_in_grid * (4 * RW);
+    if (row0 >= rows) return;  // whole wave
+    u32x2 v[RW][NG];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        int row = row0 + r * 4 + q;
+        if (row > rows - 1) row = rows - 1;  // the tail re-reads the last row
+        const bf16_t* xr = x + (size_t)row * xs + 4 * i;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) v[r][g] = *(const u32x2*)(xr + g * 64);
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float a, b;
+            row16_stats(v[r][g].x, v[r][g].y, a, b);
+            sm = __fadd_rn(sm, a);
+            sq = __fadd_rn(sq, b);
+        }
+        const int row = row0 + r * 4 + q;
+        if (i == 0 && row < rows) stats[row] = ln_from_sums(sm, sq, inv_d, eps);
+    }
+}
+
+// ... and from the slabs a residual GEMM left: slab g holds (sum, sum of squares) over columns [64 g, 64 g + 64) of every row.
+// One thread per row, the slabs added left to right like row_stats_kernel does; NG > 0: all loads issued before the first add
+// (the launch is one memory round trip long), NG = 0: any number of slabs, four at a time.
+template <int NG>
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ stats,
+                                                                 int rows, int ng, float inv_d, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float sm = 0.f, sq = 0.f;
+    if constexpr (NG > 0) {
+        float2 p[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) p[g] = part[(size_t)g * rows + row];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            sm = __fadd_rn(sm, p[g].x);
+            sq = __fadd_rn(sq, p[g].y);
+        }
+    } else {
+        for (int g0 = 0; g0 < ng; g0 += 4) {
+            float2 p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = (g0 + k < ng) ? part[(size_t)(g0 + k) * rows + row] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (g0 + k < ng) {
+                    sm = __fadd_rn(sm, p[k].x);
+                    sq = __fadd_rn(sq, p[k].y);
+                }
+        }
+    }
+    stats[row] = ln_from_sums(sm, sq, inv_d, eps);
 }
 
 // Fold a LayerNorm's affine part into the Linear that follows it. With xh = (x - mean) * rstd:
@@ -308,9 +380,43 @@ int launch_layernorm(const void* x, const float* g, const float* b, void* y, int
     return vit_set_error(VIT_E_INVALID, "layernorm: bad dtype %d", dtype);
 }
 
+// Which statistics kernel a width takes: the one-pass form (dim % 64 == 0: its bits are what the residual GEMM's row sums
+// reproduce) or the two-pass form (any dim % 8 == 0; no cancellation in the variance). VIT_AMD_STATS_ONE_PASS=0 in the
+// environment keeps the two-pass kernel for every width -- and with it the row sums of the residual epilogues off
+// (vit_capi.hip), since they could not match its bits.
+bool ln_stats_one_pass(int dim) {
+    static const bool on = !(getenv("VIT_AMD_STATS_ONE_PASS") && atoi(getenv("VIT_AMD_STATS_ONE_PASS")) == 0);
+    return on && dim % 64 == 0;
+}
+
 int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, float eps, int dtype, hipStream_t stream) {
     VIT_REQUIRE(rows > 0 && dim > 0 && dim % 8 == 0 && xs % 8 == 0 && dim <= 2048, "ln_stats: bad shape rows=%d dim=%d (multiples of 8)", rows, dim);
     VIT_REQUIRE(dtype == VIT_BF16, "ln_stats: bf16 only");
+    if (ln_stats_one_pass(dim) && xs % 4 == 0) {
+        // the one-pass form whose bits the residual GEMM's row sums reproduce (row_stats_kernel); other widths keep the
+        // two-pass kernel below. Which of the two runs depends on dim alone, never on the batch.
+        const int ng = dim / 64;
+        const bool small_r = rows < 20000;  // as below: few rows want more waves, many rows more bytes in flight per wave
+        const int rw = small_r ? 1 : 2;
+        const int blocks_r = ceil_div(rows, 16 * rw);
+        const float inv_d = 1.0f / (float)dim;
+#define VIT_ROW_STATS_CASE(NG)                                                                                                        \
+    case NG:                                                                                                                         \
+        if (small_r) hipLaunchKernelGGL((row_stats_kernel<NG, 1>), dim3(blocks_r), dim3(256), 0, stream, (const bf16_t*)x, (float2*)stats, rows, xs, inv_d, eps); \
+        else hipLaunchKernelGGL((row_stats_kernel<NG, 2>), dim3(blocks_r), dim3(256), 0, stream, (const bf16_t*)x, (float2*)stats, rows, xs, inv_d, eps);        \
+        break;
+        switch (ng) {
+            VIT_ROW_STATS_CASE(1) VIT_ROW_STATS_CASE(2) VIT_ROW_STATS_CASE(3) VIT_ROW_STATS_CASE(4) VIT_ROW_STATS_CASE(5) VIT_ROW_STATS_CASE(6)
+            VIT_ROW_STATS_CASE(7) VIT_ROW_STATS_CASE(8) VIT_ROW_STATS_CASE(9) VIT_ROW_STATS_CASE(10) VIT_ROW_STATS_CASE(11) VIT_ROW_STATS_CASE(12)
+            VIT_ROW_STATS_CASE(13) VIT_ROW_STATS_CASE(14) VIT_ROW_STATS_CASE(15) VIT_ROW_STATS_CASE(16) VIT_ROW_STATS_CASE(17) VIT_ROW_STATS_CASE(18)
+            VIT_ROW_STATS_CASE(19) VIT_ROW_STATS_CASE(20) VIT_ROW_STATS_CASE(21) VIT_ROW_STATS_CASE(22) VIT_ROW_STATS_CASE(23) VIT_ROW_STATS_CASE(24)
+            VIT_ROW_STATS_CASE(25) VIT_ROW_STATS_CASE(26) VIT_ROW_STATS_CASE(27) VIT_ROW_STATS_CASE(28) VIT_ROW_STATS_CASE(29) VIT_ROW_STATS_CASE(30)
+            VIT_ROW_STATS_CASE(31) VIT_ROW_STATS_CASE(32)
+        }
+#undef VIT_ROW_STATS_CASE
+        VIT_CHECK_HIP(hipGetLastError());
+        return VIT_OK;
+    }
     const bool small = rows < 20000;
     const int blocks = ceil_div(rows, small ? 8 : 32);  // 4 waves x R row pairs, one step per wave
     const bf16_t* xp = (const bf16_t*)x;
@@ -325,6 +431,23 @@ int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, 
         VIT_LN_STATS_CASE(5) VIT_LN_STATS_CASE(6) VIT_LN_STATS_CASE(7) VIT_LN_STATS_CASE(8)
     }
 #undef VIT_LN_STATS_CASE
+    VIT_CHECK_HIP(hipGetLastError());
+    return VIT_OK;
+}
+
+int launch_row_stats_finalize(const float* row_part, float* stats, int rows, int dim, float eps, hipStream_t stream) {
+    VIT_REQUIRE(rows > 0 && dim > 0 && dim % 64 == 0, "row_stats_finalize: bad shape rows=%d dim=%d", rows, dim);
+    const int ng = dim / 64;
+    const dim3 grid(ceil_div(rows, 256));
+    const float inv_d = 1.0f / (float)dim;
+    const float2* pp = (const float2*)row_part;
+    float2* sp = (float2*)stats;
+    switch (ng) {  // ViT-B (768), ViT-L (1024), ViT-H (1280): fully unrolled; anything else takes the loop
+        case 12: hipLaunchKernelGGL(row_stats_finalize_kernel<12>, grid, dim3(256), 0, stream, pp, sp, rows, ng, inv_d, eps); break;
+        case 16: hipLaunchKernelGGL(row_stats_finalize_kernel<16>, grid, dim3(256), 0, stream, pp, sp, rows, ng, inv_d, eps); break;
+        case 20: hipLaunchKernelGGL(row_stats_finalize_kernel<20>, grid, dim3(256), 0, stream, pp, sp, rows, ng, inv_d, eps); break;
+        default: hipLaunchKernelGGL(row_stats_finalize_kernel<0>, grid, dim3(256), 0, stream, pp, sp, rows, ng, inv_d, eps); break;
+    }
     VIT_CHECK_HIP(hipGetLastError());
     return VIT_OK;
 }

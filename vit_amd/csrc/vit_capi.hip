@@ -544,6 +544,24 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
     // folded LayerNorm at every batch size (both GEMM kernels carry the epilogue and give the same bits, so a
     // sub-batch reproduces the rows of the full batch)
     const bool fuse = ctx->ln_fuse && !ctx->fold_dirty;
+    // Row sums from the residual epilogues: the o_proj / fc2 GEMM that writes x also leaves, per 64-column group, the
+    // (sum, sum of squares) of every row it stored, and a tiny launch turns the D / 64 slabs into the statistics the next
+    // folded LayerNorm reads -- instead of a pass over x (13 us at ViT-B/16 batch 256, 24 of them per forward). Same numbers bit for bit as launch_ln_stats (one instruction sequence,
+    // vit_common.h), so which route ran is not visible in the output. The slabs live in the workspace's LayerNorm-output buffer, which a folded forward never
+    // uses. Lab switch VIT_AMD_ROW_STATS=0: always the stand-alone pass.
+    static const bool row_stats_on = !(getenv("VIT_AMD_ROW_STATS") && atoi(getenv("VIT_AMD_ROW_STATS")) == 0);
+    const bool rst = fuse && row_stats_on && T == VIT_BF16 && ln_stats_one_pass(D) && gemm_writes_row_stats(M, D, D) && gemm_writes_row_stats(M, D, F) &&
+                     (size_t)(D / 64) * M * 8 <= (size_t)M * D * es;
+    float* part = (float*)ln;
+    bool have_part = false;  // `part` holds the row sums of x (left by the GEMM that wrote it)
+    // a folded LayerNorm's statistics: the slabs through the finalising launch, or a pass over x
+    auto ln_source = [&](GemmExt& e) -> int {
+        if (have_part) VIT_TRY(launch_row_stats_finalize(part, stats, M, D, c.layer_norm_eps, stream));
+        else VIT_TRY(launch_ln_stats(x, stats, M, D, D, c.layer_norm_eps, T, stream));
+        e.ln_stats = stats;
+        have_part = false;
+        return VIT_OK;
+    };
 
     // embeddings (modeling_vit.py:129-161 / modeling_clip.py:202-218)
     const void* pix = pixels_dev;
@@ -572,8 +590,8 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
         if (fuse) {
             GemmExt e{};
             e.concurrent = concurrent;
-            e.ln_stats = stats; e.ln_colsum = ctx->folds[l].cqkv;
-            VIT_TRY(launch_ln_stats(x, stats, M, D, D, c.layer_norm_eps, T, stream));
+            e.ln_colsum = ctx->folds[l].cqkv;
+            VIT_TRY(ln_source(e));
             VIT_TRY(launch_gemm(x, ctx->folds[l].wqkv, ctx->folds[l].dqkv, nullptr, qkv, M, 3 * D, D, VIT_EPI_BIAS, T, nullptr,
                                 nullptr, stream, &e));
         } else {
@@ -584,13 +602,15 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
         GemmExt er{};  // o_proj / fc2 + residual: only the chunk hint
         er.split_k = 1;
         er.concurrent = concurrent;
+        if (rst) er.row_part = part;
         VIT_TRY(launch_gemm(cx, lw.wo, lw.bo, x, x, M, D, D, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream, &er));
+        have_part = rst;
         // x + MLP(LN2(x))    (modeling_vit.py:280-284)
         if (fuse) {
             GemmExt e{};
             e.concurrent = concurrent;
-            e.ln_stats = stats; e.ln_colsum = ctx->folds[l].c1;
-            VIT_TRY(launch_ln_stats(x, stats, M, D, D, c.layer_norm_eps, T, stream));
+            e.ln_colsum = ctx->folds[l].c1;
+            VIT_TRY(ln_source(e));
             VIT_TRY(launch_gemm(x, ctx->folds[l].w1, ctx->folds[l].d1, nullptr, h, M, F, D, act_epi, T, nullptr, nullptr, stream, &e));
         } else {
             VIT_TRY(launch_layernorm(x, lw.ln2_g, lw.ln2_b, ln, M, D, D, D, c.layer_norm_eps, T, stream));
@@ -598,7 +618,9 @@ static int forward_range(vit_ctx* ctx, const void* pixels_dev, int pixel_dtype, 
         }
         // CLIP returns the un-normed stream: let the last fc2 write it straight to hidden_out
         void* dst = (clip && last) ? hidden_out : x;
+        er.row_part = (rst && !last) ? part : nullptr;  // the last layer's output meets no folded LayerNorm
         VIT_TRY(launch_gemm(h, lw.w2, lw.b2, x, dst, M, D, F, VIT_EPI_RESIDUAL, T, nullptr, nullptr, stream, &er));
+        have_part = rst && !last;
     }
     if (!clip) {
         // final LayerNorm over all tokens; pooled = its CLS row (modeling_vit.py:385-388, no pooler)
@@ -643,6 +665,20 @@ extern "C" int vit_gemm_ln_folded(const void* x, const void* weight_folded, cons
     GemmExt e{};
     e.ln_stats = stats; e.ln_colsum = colsum;
     return launch_gemm(x, weight_folded, bias_folded, nullptr, C, M, N, K, epilogue, VIT_BF16, nullptr, nullptr, (hipStream_t)stream, &e);
+}
+
+extern "C" int vit_gemm_residual_row_stats(const void* A, const void* W, const float* bias, const void* residual, void* C,
+                                           float* row_part, int M, int N, int K, void* stream) {
+    VIT_REQUIRE(A && W && residual && C && row_part, "vit_gemm_residual_row_stats: null argument");
+    VIT_REQUIRE(gemm_writes_row_stats(M, N, K), "vit_gemm_residual_row_stats: shape M=%d N=%d K=%d is not one the persistent kernel takes (N %% 64 == 0, K %% 128 == 0, M * N >= 4 Mi)", M, N, K);
+    GemmExt e{};
+    e.row_part = row_part;
+    return launch_gemm(A, W, bias, residual, C, M, N, K, VIT_EPI_RESIDUAL, VIT_BF16, nullptr, nullptr, (hipStream_t)stream, &e);
+}
+
+extern "C" int vit_row_stats_finalize(const float* row_part, float* stats, int rows, int dim, float eps, void* stream) {
+    VIT_REQUIRE(row_part && stats, "vit_row_stats_finalize: null argument");
+    return launch_row_stats_finalize(row_part, stats, rows, dim, eps, (hipStream_t)stream);
 }
 
 extern "C" int vit_gemm_bias_act(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,

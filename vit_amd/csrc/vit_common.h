@@ -65,6 +65,48 @@ static inline int vit_cu_count(int* ncu) {
         if (_rc != VIT_OK) return _rc; \
     } while (0)
 
+// ---- LayerNorm row statistics in one pass (the folded LayerNorm of vit_forward) ----
+// Two kernels produce them and must agree bit for bit (a small batch takes the stand-alone pass, a big one gets the sums
+// from the residual epilogue of the GEMM that wrote the rows): both cut a row into groups of 64 columns, give the 16 lanes
+// of a DPP row 4 consecutive stored bf16 values each (two packed pairs d0, d1), and run THIS instruction sequence:
+// v_dot2c_f32_bf16 (exact products, fp32 accumulation: sm = ((0 + x0 + x1) + x2 + x3) in the instruction's own order), then
+// the sum over the 16 lanes by four rotate-and-add steps. Only lane 0's result is used: it is
+// (((a0 + a8) + (a12 + a4)) + ((a14 + a6) + (a10 + a2))) + (the same tree over the odd lanes). Hand-written: through the
+// DPP builtin the compiler emits a zeroed "old" register and a separate move per step (30 instructions per row instead of
+// 18); a DPP operand needs two wait states behind the VALU write of its register, which the two interleaved chains and
+// one s_nop give.
+__device__ __forceinline__ void row16_stats(unsigned d0, unsigned d1, float& sm, float& sq) {
+    sm = 0.f;
+    sq = 0.f;
+    asm("v_dot2c_f32_bf16 %0, %2, %4\n\t"
+        "v_dot2c_f32_bf16 %1, %2, %2\n\t"
+        "v_dot2c_f32_bf16 %0, %3, %4\n\t"
+        "v_dot2c_f32_bf16 %1, %3, %3\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(sm), "+v"(sq)
+        : "v"(d0), "v"(d1), "v"(0x3F803F80u));
+}
+// (sum, sum of squares) of a whole row -> (mean * rstd, rstd). One pass: var = E[x^2] - mean^2 in fp32, clamped at 0; its
+// relative error is about 2^-23 (1 + mean^2 / var) sqrt(dim), i.e. below bf16's own rounding of the inputs until
+// |mean| reaches a few hundred standard deviations. Every operation pinned (no contraction): same bits in both kernels.
+__device__ __forceinline__ float2 ln_from_sums(float sm, float sq, float inv_d, float eps) {
+    const float mean = __fmul_rn(sm, inv_d);
+    const float var = fmaxf(__fmaf_rn(sq, inv_d, -__fmul_rn(mean, mean)), 0.f);
+    const float rstd = 1.0f / sqrtf(__fadd_rn(var, eps));
+    return make_float2(__fmul_rn(mean, rstd), rstd);
+}
+
 // ---- activations (fp32 math) ----
 __device__ __forceinline__ float act_gelu_erf(float x) {
     // exact GELU: 0.5 x (1 + erf(x / sqrt 2))   (configuration_vit.py:54, ACT2FN["gelu"])
@@ -213,6 +255,10 @@ struct GemmExt {
     // the caller runs another chunk of the same forward on a second stream at the same time: keep 256-row tiles
     // (gemm_bf16_8p.hip, few-tile planner)
     int concurrent;
+    // residual epilogue of the persistent kernel (N % 64 == 0): also write, per 64-column group g and row r, the pair
+    // (sum, sum of squares) of the stored bf16 values to row_part[(g * M + r) * 2] -- N / 64 slabs of M float pairs, turned
+    // into the next folded LayerNorm's statistics by launch_row_stats_finalize (layernorm.hip)
+    float* row_part;
 };
 
 // C = epi(A W^T + bias (+res)); `patch` non-null => A is the pixel tensor, rows are patches,
@@ -259,6 +305,11 @@ int launch_gemm_bf16_8p_patch_dense(const void* A, const void* W, const float* b
                                     int K, const PatchGeom* g, hipStream_t stream);
 // LayerNorm folded into the next GEMM (layernorm.hip): per-row (mean * rstd, rstd), and the weight fold
 int launch_ln_stats(const void* x, float* stats, int rows, int dim, int64_t xs, float eps, int dtype, hipStream_t stream);
+// stats[row] from the N / 64 slabs of (sum, sum of squares) a residual GEMM wrote (GemmExt::row_part): the same numbers, bit
+// for bit, as launch_ln_stats on the rows that GEMM stored (dim % 64 == 0)
+bool gemm_writes_row_stats(int M, int N, int K);  // gemm_bf16.hip
+bool ln_stats_one_pass(int dim);                  // layernorm.hip: launch_ln_stats takes the one-pass kernel for this width
+int launch_row_stats_finalize(const float* row_part, float* stats, int rows, int dim, float eps, hipStream_t stream);
 int launch_ln_fold(const void* W, int64_t pitch, const float* gamma, const float* beta, const float* bias, void* Wg, float* c,
                    float* d, int N, int K, hipStream_t stream);
 int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t stream);
