@@ -81,15 +81,20 @@ def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
     # un-normalised rows with the row terms in its epilogue (include/vit_amd.h, vit_gemm_ln_folded)
     stats = ops.layer_norm_stats(x, cfg.layer_norm_eps)
     fqkv, f1 = ops.layer_norm_fold(wqkv, g, b, bqkv), ops.layer_norm_fold(w1, g, b, b1)
+    # the o_proj / fc2 GEMMs of vit_forward also leave the row sums of what they store (the next folded LayerNorm's statistics,
+    # DESIGN 11.10), finalised by a small launch; the statistics pass itself is left for layer 0
+    rs_out, rs_part = torch.empty_like(x), torch.empty(d // 64, m, 2, dtype=torch.float32, device=dev)
+    eps = cfg.layer_norm_eps
     specs = [  # name, launches per forward, callable, flops per launch, bytes per launch (HBM-bound kernels)
         ("gemm_qkv", L, lambda: ops.linear_ln_folded(x, fqkv, stats), 2 * m * 3 * d * d, None),
-        ("gemm_o_proj_res", L, lambda: ops.linear(x, wo, bo, residual=x), 2 * m * d * d, None),
+        ("gemm_o_proj_res", L, lambda: ops.linear_residual_row_stats(x, wo, bo, x, eps, rs_out, rs_part, finalize=False), 2 * m * d * d, None),
         ("gemm_fc1_gelu", L, lambda: ops.linear_ln_folded(x, f1, stats, cfg.hidden_act), 2 * m * f * d, None),
-        ("gemm_fc2_res", L, lambda: ops.linear(hid, w2, bo, residual=x), 2 * m * d * f, None),
+        ("gemm_fc2_res", L, lambda: ops.linear_residual_row_stats(hid, w2, bo, x, eps, rs_out, rs_part, finalize=False), 2 * m * d * f, None),
+        ("row_stats_finalize", 2 * L - 2, lambda: ops.row_stats_finalize(rs_part, eps, stats), None, m * (d // 64) * 8 + m * 8),
         # attention at N = 197, dh = 64 is 99 FLOP per byte (Q, K, V read once, output written once)
         # against a machine balance of ~310: its roofline is HBM; both figures are reported
         ("attention", L, lambda: ops.attention(qkv, h), 4 * batch * h * n * n * cfg.head_dim, 4 * m * d * 2),
-        ("layernorm_stats", 2 * L, lambda: ops.layer_norm_stats(x, cfg.layer_norm_eps), None, m * d * 2 + m * 8),
+        ("layernorm_stats", 2, lambda: ops.layer_norm_stats(x, cfg.layer_norm_eps), None, m * d * 2 + m * 8),
         ("layernorm", 1, lambda: ops.layer_norm(x, g, b, cfg.layer_norm_eps), None, 2 * m * d * 2),
         ("patch_embed", 1, lambda: ops.patch_embed(px, pw, bo, cls, pos, cfg.patch_size),
          2 * batch * cfg.num_patches * cfg.patch_dim * d, None),

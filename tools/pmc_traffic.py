@@ -17,7 +17,8 @@ GROUPS = [  # bench name, substring of the kernel name
     ("gemm_o_proj_res+gemm_fc2_res", "gemm8p_persist_kernel<3, 0, false"),
     ("patch_embed", "gemm8p_persist_kernel<100, 0, false"),
     ("attention", "attention_dh64_kernel"),
-    ("layernorm_stats", "ln_stats_kernel"),
+    ("layernorm_stats", "row_stats_kernel"),
+    ("row_stats_finalize", "row_stats_finalize_kernel"),
     ("layernorm", "layernorm_kernel"),
 ]
 

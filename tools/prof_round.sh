@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_${PROF_TAG:-r03b}
+O=gpurun_out/prof_${PROF_TAG:-r03c}
 rm -rf $O && mkdir -p $O
 export VIT_AMD_STREAMS=1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $O/s1.log 2>&1

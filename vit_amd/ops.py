@@ -93,8 +93,17 @@ def linear_ln_folded(x: torch.Tensor, folded, stats: torch.Tensor, activation: s
     return out
 
 
+def row_stats_finalize(row_part: torch.Tensor, eps: float, stats: torch.Tensor | None = None) -> torch.Tensor:
+    """(mean * rstd, rstd) per row from the ``[dim / 64, rows, 2]`` fp32 row sums a residual GEMM left."""
+    ng, m, _ = row_part.shape
+    if stats is None:
+        stats = torch.empty(m, 2, dtype=torch.float32, device=row_part.device)
+    _lib.check(_lib.load().vit_row_stats_finalize(row_part.data_ptr(), stats.data_ptr(), m, ng * 64, float(eps), _stream()))
+    return stats
+
+
 def linear_residual_row_stats(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor,
-                              eps: float):
+                              eps: float, out=None, part=None, finalize: bool = True):
     """``F.linear(x, weight, bias) + residual`` [bf16] together with the folded-LayerNorm statistics of the rows it stored
     (what ``layer_norm_stats(out, eps)`` computes, bit for bit): the residual epilogue leaves per-64-column row sums and a
     small launch finalises them (modeling_vit.py:236 + :277 -> :281, :252 + :284 -> :274). Returns (out, stats, row_part)."""
@@ -106,12 +115,13 @@ def linear_residual_row_stats(x: torch.Tensor, weight: torch.Tensor, bias: torch
     if w.shape[1] != k:
         raise ValueError(f"linear_residual_row_stats: x has {k} features, weight expects {w.shape[1]}")
     m = x.numel() // k
-    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
-    part = torch.empty(max(n // 64, 1), m, 2, dtype=torch.float32, device=x.device)
-    stats = torch.empty(m, 2, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    if part is None:
+        part = torch.empty(max(n // 64, 1), m, 2, dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().vit_gemm_residual_row_stats(x.data_ptr(), w.data_ptr(), _ptr(b), r.data_ptr(), out.data_ptr(),
                                                        part.data_ptr(), m, n, k, _stream()))
-    _lib.check(_lib.load().vit_row_stats_finalize(part.data_ptr(), stats.data_ptr(), m, n, float(eps), _stream()))
+    stats = row_stats_finalize(part, eps) if finalize else None
     return out, stats, part
 
 
