@@ -42,6 +42,10 @@
 //    edges, no branches); the residual tile is fetched up front into the dead fragment
 //    registers. Measured on MI355X (tools/store_lab.hip): this store shape moves a 128 KiB tile
 //    in 2.3 us per CU, the natural 16-rows-x-64-B MFMA shape needs 4.5 us.
+//  * Residual epilogue with row sums (template flag RST; vit_forward's o_proj / fc2): a wave's 64 columns of a tile are one
+//    64-column group of the output row, so it also leaves (sum, sum of squares) of the bf16 values it stores, per row and
+//    group -- the next folded LayerNorm's statistics without a pass over the rows (row16_stats in vit_common.h: the same
+//    instruction sequence as the stand-alone statistics kernel, hence the same bits).
 #include "vit_common.h"
 #include <type_traits>
 #include <stdlib.h>
