@@ -83,18 +83,25 @@ def kernel_rooflines(cfg: ViTConfig, batch: int, dev):
     fqkv, f1 = ops.layer_norm_fold(wqkv, g, b, bqkv), ops.layer_norm_fold(w1, g, b, b1)
     # the o_proj / fc2 GEMMs of vit_forward also leave the row sums of what they store (the next folded LayerNorm's statistics,
     # DESIGN 11.10), finalised by a small launch; the statistics pass itself is left for layer 0
-    rs_out, rs_part = torch.empty_like(x), torch.empty(d // 64, m, 2, dtype=torch.float32, device=dev)
+    rs_out, rs_part = torch.empty_like(x), torch.empty(max(d // 64, 1), m, 2, dtype=torch.float32, device=dev)
     eps = cfg.layer_norm_eps
+    # (small batches: vit_forward takes the plain residual GEMM and the statistics pass, and so does this list)
+    row_sums = d % 64 == 0 and d % 128 == 0 and f % 128 == 0 and m * d >= 64 * 256 * 256
+
+    def res_gemm(a, w):
+        if row_sums:
+            return ops.linear_residual_row_stats(a, w, bo, x, eps, rs_out, rs_part, finalize=False)
+        return ops.linear(a, w, bo, residual=x)
     specs = [  # name, launches per forward, callable, flops per launch, bytes per launch (HBM-bound kernels)
         ("gemm_qkv", L, lambda: ops.linear_ln_folded(x, fqkv, stats), 2 * m * 3 * d * d, None),
-        ("gemm_o_proj_res", L, lambda: ops.linear_residual_row_stats(x, wo, bo, x, eps, rs_out, rs_part, finalize=False), 2 * m * d * d, None),
+        ("gemm_o_proj_res", L, lambda: res_gemm(x, wo), 2 * m * d * d, None),
         ("gemm_fc1_gelu", L, lambda: ops.linear_ln_folded(x, f1, stats, cfg.hidden_act), 2 * m * f * d, None),
-        ("gemm_fc2_res", L, lambda: ops.linear_residual_row_stats(hid, w2, bo, x, eps, rs_out, rs_part, finalize=False), 2 * m * d * f, None),
-        ("row_stats_finalize", 2 * L - 2, lambda: ops.row_stats_finalize(rs_part, eps, stats), None, m * (d // 64) * 8 + m * 8),
+        ("gemm_fc2_res", L, lambda: res_gemm(hid, w2), 2 * m * d * f, None),
+        ("row_stats_finalize", (2 * L - 2) if row_sums else 0, lambda: ops.row_stats_finalize(rs_part, eps, stats), None, m * max(d // 64, 1) * 8 + m * 8),
         # attention at N = 197, dh = 64 is 99 FLOP per byte (Q, K, V read once, output written once)
         # against a machine balance of ~310: its roofline is HBM; both figures are reported
         ("attention", L, lambda: ops.attention(qkv, h), 4 * batch * h * n * n * cfg.head_dim, 4 * m * d * 2),
-        ("layernorm_stats", 2, lambda: ops.layer_norm_stats(x, cfg.layer_norm_eps), None, m * d * 2 + m * 8),
+        ("layernorm_stats", 2 if row_sums else 2 * L, lambda: ops.layer_norm_stats(x, cfg.layer_norm_eps), None, m * d * 2 + m * 8),
         ("layernorm", 1, lambda: ops.layer_norm(x, g, b, cfg.layer_norm_eps), None, 2 * m * d * 2),
         ("patch_embed", 1, lambda: ops.patch_embed(px, pw, bo, cls, pos, cfg.patch_size),
          2 * batch * cfg.num_patches * cfg.patch_dim * d, None),
