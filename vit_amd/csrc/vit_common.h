@@ -73,8 +73,9 @@ static inline int vit_cu_count(int* ncu) {
 // the sum over the 16 lanes by four rotate-and-add steps. Only lane 0's result is used: it is
 // (((a0 + a8) + (a12 + a4)) + ((a14 + a6) + (a10 + a2))) + (the same tree over the odd lanes). Hand-written: through the
 // DPP builtin the compiler emits a zeroed "old" register and a separate move per step (30 instructions per row instead of
-// 18); a DPP operand needs two wait states behind the VALU write of its register, which the two interleaved chains and
-// one s_nop give.
+// 18). Inline asm gets no hazard handling from the compiler: a DPP operand needs two wait states behind the VALU write of its
+// register (the two interleaved chains + s_nop 0), and a VALU read of a v_dot2c result three (s_nop 1 + the other chain's
+// instruction); a v_dot2c accumulating onto its own kind's result needs none.
 __device__ __forceinline__ void row16_stats(unsigned d0, unsigned d1, float& sm, float& sq) {
     sm = 0.f;
     sq = 0.f;
